@@ -1,0 +1,202 @@
+/*
+ * seekmer_hip.h -- C ABI of the MI355X (gfx950) engine behind `seekmer infer`.
+ *
+ * The reference (GuanLab/seekmer) has no FFI seam on this path: its Python
+ * layer calls Cython extension classes directly.  Every entry point below
+ * names the reference interface it replaces (file:line under
+ * /root/reference); INTEGRATION.md shows the ctypes binding a maintainer
+ * would add to the reference.  Plain pointers and sizes only; no exceptions
+ * cross the boundary: every function returns an int status (0 = SKM_OK) and
+ * skm_last_error() gives the message for the calling thread.
+ *
+ * Two shared libraries implement it:
+ *   libseekmer_hip.so   -- everything that touches the GPU (skm_index_*,
+ *                          skm_mapper_*, skm_quant_*, skm_comm_*, skm_device_*)
+ *   libseekmer_host.so  -- host-side native code with no GPU dependency
+ *                          (skm_build_*, skm_fastq_*, skm_synth_*)
+ */
+#ifndef SEEKMER_HIP_H
+#define SEEKMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKM_OK 0
+#define SKM_ERR_ARG 1          /* bad argument */
+#define SKM_ERR_HIP 2          /* HIP runtime error (message has the call) */
+#define SKM_ERR_NO_DEVICE 3    /* no usable GPU */
+#define SKM_ERR_COLLISION 4    /* two different class tuples share a 64-bit key */
+#define SKM_ERR_STATE 5        /* call order / capacity */
+#define SKM_ERR_IO 6
+#define SKM_ERR_UNDEFINED 7    /* the reference's behaviour is undefined for this input */
+#define SKM_ERR_COMM 8         /* RCCL error */
+
+#define SKM_KMER_SIZE 25            /* seekmer/_kmer.pxd:9-17 */
+#define SKM_MAX_FRAGMENT_LENGTH 2000 /* seekmer/_mapper.pyx:18-20 */
+
+/* Array element layouts are the reference's numpy dtypes:
+ *   kmers    {u64 kmer; i32 entry; i32 offset}                     16 B  seekmer/_common.pxd:15-17
+ *   contigs  {i64 offset,length; u64 first_kmer,last_kmer;
+ *             i64 target_offset,target_count}                      48 B  seekmer/_common.pxd:21-27
+ *   sequences  char 'ACGT'                                               seekmer/_index_builder.pyx:568
+ *   targets  {i32 entry; i32 offset}                                8 B  seekmer/_coordinate.pxd:8-10 */
+
+const char *skm_last_error(void);
+/* number of visible GPUs; SKM_ERR_NO_DEVICE when there is none */
+int skm_device_count(int *count);
+
+/* ------------------------------------------------------------------ index
+ * Replaces the memoryview binding of KMerIndex.__init__
+ * (seekmer/_common.pyx:21-48).  Host arrays are borrowed for the call and
+ * copied to HBM (the pooled sequences are re-packed to 2 bits per base); the
+ * handle owns device memory only. */
+typedef struct skm_index skm_index;
+int skm_index_create(const void *kmers, int64_t n_slots,
+                     const void *contigs, int64_t n_contigs,
+                     const char *sequences, int64_t n_bases,
+                     const void *targets, int64_t n_targets,
+                     int device, skm_index **out);
+int skm_index_destroy(skm_index *index);
+/* info[0]=n_slots [1]=n_contigs [2]=n_bases [3]=n_targets [4]=max target_count
+ * [5]=device bytes held */
+int skm_index_info(const skm_index *index, int64_t info[6]);
+
+/* ------------------------------------------------------------------ mapper
+ * One handle = ReadMapper + the MapResult it feeds
+ * (seekmer/_mapper.pyx:31-105; seekmer/mapper.py:40-115): it maps batches
+ * and accumulates the equivalence-class counter and the fragment-length
+ * histogram in HBM. */
+typedef struct skm_mapper skm_mapper;
+int skm_mapper_create(skm_index *index, skm_mapper **out);
+int skm_mapper_destroy(skm_mapper *mapper);
+
+/* ReadMapper.__call__ for one batch (seekmer/_mapper.pyx:73-101): `bases`
+ * holds the reads back to back, read r = [offsets[r], offsets[r+1]);
+ * n_reads = n_units (single-ended) or 2*n_units (paired: reads 2u, 2u+1 are
+ * the mates of unit u, the layout feed_pair_ended_reads yields,
+ * seekmer/common.py:161-197).  Host buffers; copied to the GPU. */
+int skm_mapper_map_batch(skm_mapper *mapper, const char *bases,
+                         const int64_t *offsets, int64_t n_units, int paired);
+/* Same with the batch already resident in HBM (device pointers; max_read_len
+ * must bound every read length). */
+int skm_mapper_map_batch_device(skm_mapper *mapper, const void *d_bases,
+                                const void *d_offsets, int64_t n_units,
+                                int paired, int32_t max_read_len);
+/* Per-unit results of the LAST batch (what ReadMapper keeps in `results` and
+ * `span`, seekmer/_mapper.pyx:83-99): any pointer may be NULL.  counts[u] =
+ * number of targets, entries = signed target entries of all units back to
+ * back in unit order (cap_entries bounds it; *n_entries = needed size). */
+int skm_mapper_last_batch(skm_mapper *mapper, int32_t *begin, int32_t *end,
+                          int32_t *anchor_entry, int32_t *anchor_offset,
+                          int32_t *counts, int32_t *entries,
+                          int64_t cap_entries, int64_t *n_entries);
+/* Counter sizes (MapResult.summarize, seekmer/mapper.py:77-104):
+ * summary[0]=C classes [1]=M (class,target) rows [2]=unaligned [3]=total units */
+int skm_mapper_summary(skm_mapper *mapper, int64_t summary[4]);
+/* Classes in first-seen order (collections.Counter insertion order under -j1):
+ * class_offsets[C+1], class_targets[M] unsigned ids in tuple order,
+ * class_counts[C], first_seen[C] (global unit index), fld[2000]. */
+int skm_mapper_export(skm_mapper *mapper, int64_t *class_offsets,
+                      int32_t *class_targets, int64_t *class_counts,
+                      int64_t *first_seen, int64_t *fld);
+/* MapResult.merge_fragment_lengths / Counter.update with foreign data: merge
+ * an exported table (e.g. another GPU's) into this one. */
+int skm_mapper_merge(skm_mapper *mapper, int64_t n_classes,
+                     const int64_t *class_offsets, const int32_t *class_targets,
+                     const int64_t *class_counts, const int64_t *first_seen,
+                     int64_t unaligned, const int64_t *fld);
+int skm_mapper_clear(skm_mapper *mapper);           /* MapResult.clear, mapper.py:143-145 */
+/* stats[0]=pack kernel ns [1]=map kernel ns [2]=class kernels ns [3]=batches
+ * [4]=units (HIP-event times accumulated over batches on the mapper stream) */
+int skm_mapper_timing(skm_mapper *mapper, double stats[8]);
+/* Access counters of the instrumented build of the map kernel (they define the
+ * algorithmic bytes): enable, map, then read.  out[0]=reads
+ * [1]=read bases [2]=lookups [3]=slots probed [4]=ContigEntry reads [5]=target
+ * entries copied [6]=target entries merged [7]=8-base fetches [8]=merges
+ * [9]=tuple ids. */
+int skm_mapper_set_stats(skm_mapper *mapper, int enable);
+int skm_mapper_access_stats(skm_mapper *mapper, int64_t out[16]);
+
+/* ------------------------------------------------------------ quantification
+ * MapResult.effective_lengths (seekmer/mapper.py:134-141). */
+int skm_effective_lengths(int device, const int64_t *fld, const double *lengths,
+                          int64_t n_tx, double *out);
+
+/* Device-resident class table for infer.em / infer.quantify
+ * (seekmer/infer.py:88-168).  class_counts are f8 as in
+ * SummarizedResult.class_count. */
+typedef struct skm_quant skm_quant;
+int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
+                     const int64_t *class_offsets, const int32_t *class_targets,
+                     const double *class_counts, skm_quant **out);
+/* Same, taking the table straight from a mapper without leaving HBM. */
+int skm_quant_create_from_mapper(skm_mapper *mapper, int64_t n_tx, skm_quant **out);
+int skm_quant_destroy(skm_quant *quant);
+/* infer.em (seekmer/infer.py:133-168): x inout [n_tx], l = effective lengths.
+ * Stops on the reference criterion max_{x'>x_floor} |x'-x|/x' <= rel_tol
+ * (0.01, 1e-8 in the reference); fixed_iters>0 runs exactly that many steps
+ * instead; max_iters>0 caps.  *iters = steps done.  Returns SKM_ERR_UNDEFINED
+ * where numpy would raise (no x' > x_floor). */
+int skm_quant_em(skm_quant *quant, double *x, const double *l, double rel_tol,
+                 double x_floor, int64_t max_iters, int64_t fixed_iters,
+                 int64_t *iters);
+/* One bootstrap replicate set (seekmer/infer.py:79-82,108-111): n_boot
+ * multinomial resamples of the class counts (counter-based RNG, `seed`), EM
+ * from x0 each; out[n_boot][n_tx] raw EM results (before TPM scaling);
+ * counts_out (optional) [n_boot][C] the resampled counts. */
+int skm_quant_bootstrap(skm_quant *quant, int64_t n_boot, uint64_t seed,
+                        const double *x0, const double *l, double rel_tol,
+                        double x_floor, int64_t max_iters, double *out,
+                        int64_t *counts_out, int64_t *iters_out);
+/* EM with externally supplied class counts (parity of the bootstrap EM leg). */
+int skm_quant_set_counts(skm_quant *quant, const double *class_counts);
+/* timing[0]=EM kernel ns total [1]=iterations [2]=launches */
+int skm_quant_timing(skm_quant *quant, double timing[4]);
+
+/* ---------------------------------------------------------------- multi-GPU
+ * Not in the reference (single process).  Reads shard across ranks; the only
+ * data-path collective is one all-reduce(sum) of f64[n_tx] per EM step. */
+int skm_comm_unique_id(void *id128);                 /* rank 0: 128-byte id */
+int skm_quant_comm_init(skm_quant *quant, const void *id128, int rank, int world);
+int skm_quant_comm_destroy(skm_quant *quant);
+
+/* ============================ libseekmer_host.so ========================== */
+
+/* ContigAssembler.assemble (seekmer/_index_builder.pyx:105-150): pooled
+ * transcript bases, transcript i = [seq_offsets[i], seq_offsets[i+1]). */
+typedef struct skm_built skm_built;
+int skm_build_index(const char *pool, const int64_t *seq_offsets, int64_t n_seqs,
+                    int n_threads, skm_built **out);
+/* sizes[0]=n_slots [1]=n_contigs [2]=n_bases [3]=n_targets */
+int skm_built_sizes(const skm_built *b, int64_t sizes[4]);
+int skm_built_copy(const skm_built *b, void *kmers, void *contigs,
+                   char *sequences, void *targets);
+int skm_built_free(skm_built *b);
+
+/* feed_single_ended_reads / feed_pair_ended_reads (seekmer/common.py:126-197)
+ * as a native batch packer over already-decompressed FASTQ text. */
+typedef struct skm_fastq skm_fastq;
+int skm_fastq_open(const char *const *paths, int n_paths, int paired,
+                   int64_t batch_units, skm_fastq **out);
+/* next batch: *n_units = 0 at end.  Buffers are owned by the reader and stay
+ * valid until the next call.  names: '\n'-separated. */
+int skm_fastq_next(skm_fastq *reader, int64_t *n_units, const char **bases,
+                   const int64_t **offsets, const char **names,
+                   const int64_t **name_offsets);
+int skm_fastq_close(skm_fastq *reader);
+
+/* Seeded synthetic data; integer arithmetic only. */
+int skm_synth_transcriptome(uint64_t seed, int64_t n_genes, int64_t *n_tx,
+                            char **pool, int64_t **offsets);
+int skm_synth_free(void *p);
+int skm_synth_reads(uint64_t seed, const char *pool, const int64_t *tx_offsets,
+                    int64_t n_tx, int64_t first_unit, int64_t n_units,
+                    int read_len, int paired, int n_threads, char *bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

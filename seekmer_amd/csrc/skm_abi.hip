@@ -1,0 +1,1052 @@
+// C ABI of libseekmer_hip.so (declared in include/seekmer_hip.h): handle
+// management, HBM buffers, stream/event plumbing and the launch sequences.
+// No torch types, no exceptions across the boundary.
+#include "../../include/seekmer_hip.h"
+#include "skm_kernels.h"
+
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace skm;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(SKM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define SKM_TRY(call)          \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != SKM_OK) return rc_; \
+    } while (0)
+
+// device buffer that only ever grows
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;      // elements
+    int ensure(size_t n, bool keep = false, hipStream_t stream = nullptr)
+    {
+        if (n <= cap) return SKM_OK;
+        size_t want = std::max(n, cap + cap / 2);
+        T *q = nullptr;
+        HIP_TRY(hipMalloc((void **)&q, want * sizeof(T)));
+        if (keep && p && cap) {
+            HIP_TRY(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        if (p) HIP_TRY(hipFree(p));
+        p = q;
+        cap = want;
+        return SKM_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t bytes() const { return cap * sizeof(T); }
+};
+
+int set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return SKM_OK;
+}
+
+}  // namespace
+
+struct skm_index {
+    int device = 0;
+    DevIndex d{};
+    void *kmers = nullptr, *contigs = nullptr, *seq2 = nullptr, *targets = nullptr;
+    int64_t n_slots = 0, bytes = 0;
+    int cu_count = 256;
+};
+
+struct skm_mapper {
+    skm_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::mutex mu;
+    // class table
+    ClassTable t{};
+    DBuf<ClassSlot> slots;
+    DBuf<int32_t> arena_len;
+    DBuf<int32_t> arena;
+    DBuf<unsigned long long> counters;   // [0]=arena_cursor [1]=n_classes [2]=n_unaligned [3]=n_units [8..2007]=fld
+    DBuf<int> error;
+    // batch buffers
+    DBuf<uint8_t> bases;
+    DBuf<int64_t> offsets;
+    DBuf<uint64_t> codes;
+    DBuf<uint32_t> acgt;
+    DBuf<int32_t> workspace;
+    DBuf<int32_t> unit_begin, unit_end, unit_count;
+    DBuf<Coord> unit_anchor;
+    DBuf<int64_t> unit_offset, unit_slot;
+    DBuf<uint64_t> unit_key;
+    DBuf<int32_t> unit_entries;
+    DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
+    int grid_blocks = 0;
+    int64_t units_done = 0;
+    int64_t last_units = 0, last_ids = 0;
+    int64_t host_classes = 0, host_arena_used = 0;
+    bool want_stats = false;
+    double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
+    unsigned long long stats_total[16] = {0};
+};
+
+struct skm_quant {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::mutex mu;
+    int64_t n_tx = 0, n_classes = 0, n_ids = 0;
+    DBuf<int64_t> cls_offset;
+    DBuf<int32_t> cls_len;
+    DBuf<int32_t> ids;
+    DBuf<double> cls_count, cls_count_saved;
+    DBuf<double> eff_len, x0, x1, acc;
+    DBuf<unsigned long long> ctl, cum, draw;
+    bool have_cum = false;
+    double n_total = 0;
+    // RCCL (loaded lazily)
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    double t_em_ns = 0, iters_total = 0, launches = 0;
+};
+
+// ------------------------------------------------------------------- errors
+extern "C" const char *skm_last_error(void) { return g_error.c_str(); }
+
+extern "C" int skm_device_count(int *count)
+{
+    if (!count) return fail(SKM_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *count = 0;
+        return fail(SKM_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SKM_OK;
+}
+
+// -------------------------------------------------------------------- index
+extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *contigs,
+                                int64_t n_contigs, const char *sequences, int64_t n_bases,
+                                const void *targets, int64_t n_targets, int device,
+                                skm_index **out)
+{
+    if (!kmers || !contigs || !sequences || !targets || !out)
+        return fail(SKM_ERR_ARG, "NULL array");
+    if (n_slots <= 0 || (n_slots & (n_slots - 1)) || n_slots > (1LL << 31))
+        return fail(SKM_ERR_ARG, "k-mer table size %lld is not a power of two <= 2^31", (long long)n_slots);
+    if (n_contigs <= 0 || n_bases < ALIGN_LENGTH || n_targets < 0 || n_bases >= (1LL << 31))
+        return fail(SKM_ERR_ARG, "bad index sizes");
+    int n_dev = 0;
+    SKM_TRY(skm_device_count(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(SKM_ERR_ARG, "device %d out of range", device);
+    SKM_TRY(set_device(device));
+
+    // host-side validation: every shape the kernels index with must be in range
+    const ContigEntry *hc = (const ContigEntry *)contigs;
+    int64_t max_tc = 0;
+    for (int64_t c = 0; c < n_contigs; ++c) {
+        if (hc[c].offset < 0 || hc[c].length < 0 || hc[c].offset + hc[c].length > n_bases
+                || hc[c].target_offset < 0 || hc[c].target_length < 0
+                || hc[c].target_offset + hc[c].target_length > n_targets)
+            return fail(SKM_ERR_ARG, "contig %lld points outside the pooled arrays", (long long)c);
+        max_tc = std::max<int64_t>(max_tc, hc[c].target_length);
+    }
+    const IndexEntry *hk = (const IndexEntry *)kmers;
+    int64_t empty = 0;
+    for (int64_t i = 0; i < n_slots; ++i) {
+        if (hk[i].kmer == KMER_INVALID) { ++empty; continue; }
+        const int32_t e = hk[i].pos.entry < 0 ? ~hk[i].pos.entry : hk[i].pos.entry;
+        if (hk[i].pos.offset >= 0) {
+            if (e < 0 || e >= n_contigs || hk[i].pos.offset + K > hc[e].length)
+                return fail(SKM_ERR_ARG, "k-mer slot %lld points outside its contig", (long long)i);
+        }
+    }
+    if (empty == 0) return fail(SKM_ERR_ARG, "k-mer table has no empty slot");
+
+    skm_index *ix = new skm_index();
+    ix->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    ix->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int64_t n_words = (n_bases + 31) / 32 + 1;
+    char *d_ascii = nullptr;
+    HIP_TRY(hipMalloc(&ix->kmers, (size_t)n_slots * sizeof(IndexEntry)));
+    HIP_TRY(hipMalloc(&ix->contigs, (size_t)n_contigs * sizeof(ContigEntry)));
+    HIP_TRY(hipMalloc(&ix->targets, (size_t)std::max<int64_t>(n_targets, 1) * sizeof(Coord)));
+    HIP_TRY(hipMalloc(&ix->seq2, (size_t)n_words * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&d_ascii, (size_t)n_bases));
+    HIP_TRY(hipMemcpy(ix->kmers, kmers, (size_t)n_slots * sizeof(IndexEntry), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ix->contigs, contigs, (size_t)n_contigs * sizeof(ContigEntry), hipMemcpyHostToDevice));
+    if (n_targets)
+        HIP_TRY(hipMemcpy(ix->targets, targets, (size_t)n_targets * sizeof(Coord), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ascii, sequences, (size_t)n_bases, hipMemcpyHostToDevice));
+    launch_pack_sequences(d_ascii, n_bases, (uint64_t *)ix->seq2, n_words, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(d_ascii));
+    ix->n_slots = n_slots;
+    ix->d.kmers = (const IndexEntry *)ix->kmers;
+    ix->d.slot_mask = (uint32_t)(n_slots - 1);
+    ix->d.contigs = (const ContigEntry *)ix->contigs;
+    ix->d.n_contigs = n_contigs;
+    ix->d.seq2 = (const uint64_t *)ix->seq2;
+    ix->d.n_bases = n_bases;
+    ix->d.targets = (const Coord *)ix->targets;
+    ix->d.n_targets = n_targets;
+    ix->d.max_target_count = (int32_t)std::max<int64_t>(max_tc, 1);
+    ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(ContigEntry)
+                + n_targets * (int64_t)sizeof(Coord) + n_words * 8;
+    *out = ix;
+    return SKM_OK;
+}
+
+extern "C" int skm_index_destroy(skm_index *ix)
+{
+    if (!ix) return SKM_OK;
+    (void)hipSetDevice(ix->device);
+    (void)hipFree(ix->kmers); (void)hipFree(ix->contigs); (void)hipFree(ix->targets); (void)hipFree(ix->seq2);
+    delete ix;
+    return SKM_OK;
+}
+
+extern "C" int skm_index_info(const skm_index *ix, int64_t info[6])
+{
+    if (!ix || !info) return fail(SKM_ERR_ARG, "NULL argument");
+    info[0] = ix->n_slots;
+    info[1] = ix->d.n_contigs;
+    info[2] = ix->d.n_bases;
+    info[3] = ix->d.n_targets;
+    info[4] = ix->d.max_target_count;
+    info[5] = ix->bytes;
+    return SKM_OK;
+}
+
+// ------------------------------------------------------------------- mapper
+namespace {
+
+constexpr int CTR_ARENA = 0, CTR_CLASSES = 1, CTR_UNALIGNED = 2, CTR_UNITS = 3, CTR_FLD = 8;
+constexpr int CTR_WORDS = 8 + MAX_FRAGMENT_LENGTH;
+constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2064;
+
+void bind_table(skm_mapper *m, uint64_t n_slots)
+{
+    m->t.slots = m->slots.p;
+    m->t.slot_mask = n_slots - 1;
+    m->t.arena = m->arena.p;
+    m->t.arena_len = m->arena_len.p;
+    m->t.arena_capacity = (int64_t)m->arena.cap;
+    m->t.arena_cursor = m->counters.p + CTR_ARENA;
+    m->t.n_classes = m->counters.p + CTR_CLASSES;
+    m->t.n_unaligned = m->counters.p + CTR_UNALIGNED;
+    m->t.n_units = m->counters.p + CTR_UNITS;
+    m->t.global_fld = m->counters.p + CTR_FLD;
+    m->t.error = m->error.p;
+}
+
+int table_reset(skm_mapper *m, uint64_t n_slots)
+{
+    SKM_TRY(m->slots.ensure(n_slots));
+    SKM_TRY(m->arena_len.ensure(n_slots));
+    SKM_TRY(m->arena.ensure(1 << 20));
+    SKM_TRY(m->counters.ensure(CTR_WORDS));
+    SKM_TRY(m->error.ensure(1));
+    HIP_TRY(hipMemsetAsync(m->counters.p, 0, CTR_WORDS * sizeof(unsigned long long), m->stream));
+    HIP_TRY(hipMemsetAsync(m->error.p, 0, sizeof(int), m->stream));
+    bind_table(m, n_slots);
+    launch_class_init(m->t, m->stream);
+    HIP_TRY(hipGetLastError());
+    m->host_classes = 0;
+    m->host_arena_used = 0;
+    m->units_done = 0;
+    return SKM_OK;
+}
+
+// grow the class table so that `extra` more classes keep the load below 0.7
+int table_reserve(skm_mapper *m, int64_t extra)
+{
+    uint64_t n_slots = m->t.slot_mask + 1;
+    uint64_t need = n_slots;
+    while ((double)(m->host_classes + extra) > 0.7 * (double)need) need <<= 1;
+    if (need == n_slots) return SKM_OK;
+    DBuf<ClassSlot> new_slots;
+    DBuf<int32_t> new_len;
+    SKM_TRY(new_slots.ensure(need));
+    SKM_TRY(new_len.ensure(need));
+    ClassTable to = m->t;
+    to.slots = new_slots.p;
+    to.arena_len = new_len.p;
+    to.slot_mask = need - 1;
+    launch_class_init(to, m->stream);
+    launch_class_rehash(m->t, to, m->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->slots.release();
+    m->arena_len.release();
+    m->slots = new_slots;
+    m->arena_len = new_len;
+    bind_table(m, need);
+    return SKM_OK;
+}
+
+int read_error(skm_mapper *m)
+{
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, m->error.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (err == SKM_ERR_COLLISION)
+        return fail(SKM_ERR_COLLISION, "two different class tuples share a 64-bit key");
+    if (err) return fail(err, "class table kernel reported error %d", err);
+    return SKM_OK;
+}
+
+int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_offsets,
+                       int64_t n_units, int paired, int max_len)
+{
+    skm_index *ix = m->ix;
+    const int64_t n_reads = paired ? 2 * n_units : n_units;
+    const int words = (max_len + 31) / 32 + 1;
+    m->last_units = n_units;
+    m->last_ids = 0;
+    if (n_units == 0) return SKM_OK;
+
+    SKM_TRY(m->codes.ensure((size_t)n_reads * words + 2));
+    SKM_TRY(m->acgt.ensure((size_t)n_reads * words + 2));
+    SKM_TRY(m->unit_begin.ensure(n_units));
+    SKM_TRY(m->unit_end.ensure(n_units));
+    SKM_TRY(m->unit_count.ensure(n_units));
+    SKM_TRY(m->unit_anchor.ensure(n_units));
+    SKM_TRY(m->unit_offset.ensure(n_units));
+    SKM_TRY(m->unit_slot.ensure(n_units));
+    SKM_TRY(m->unit_key.ensure(n_units));
+    SKM_TRY(m->unit_entries.ensure(std::max<size_t>((size_t)n_units * 8, 1 << 16)));
+    SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
+
+    // launch geometry: at most 6 blocks of 256 lanes per CU (the kernel's
+    // occupancy), fewer when the interleaved list workspace would not fit
+    const int regions = paired ? 2 : 1;
+    int64_t blocks = std::min<int64_t>((n_units + 255) / 256, (int64_t)ix->cu_count * 6);
+    const int64_t ws_budget = 16LL << 30;
+    const int64_t per_thread = (int64_t)regions * ix->d.max_target_count * 4;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, ws_budget / (per_thread * 256)));
+    m->grid_blocks = (int)blocks;
+    SKM_TRY(m->workspace.ensure((size_t)(blocks * 256) * regions * ix->d.max_target_count));
+
+    MapBatch b{};
+    b.codes = m->codes.p;
+    b.acgt = m->acgt.p;
+    b.offsets = d_offsets;
+    b.n_units = n_units;
+    b.words_per_read = words;
+    b.paired = paired;
+    b.workspace = m->workspace.p;
+    b.unit_begin = m->unit_begin.p;
+    b.unit_end = m->unit_end.p;
+    b.unit_anchor = m->unit_anchor.p;
+    b.unit_count = m->unit_count.p;
+    b.unit_offset = m->unit_offset.p;
+    b.unit_key = m->unit_key.p;
+    b.ids_cursor = m->batch_ctl.p + BC_IDS;
+    b.fld = m->batch_ctl.p + BC_FLD;
+    b.stats = m->batch_ctl.p + BC_STATS;
+
+    HIP_TRY(hipEventRecord(m->ev[0], m->stream));
+    launch_pack_reads(d_bases, d_offsets, n_reads, words, m->codes.p, m->acgt.p, m->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev[1], m->stream));
+    unsigned long long ids = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        b.unit_entries = m->unit_entries.p;
+        b.ids_capacity = (int64_t)m->unit_entries.cap;
+        HIP_TRY(hipMemsetAsync(m->batch_ctl.p, 0, BC_WORDS * sizeof(unsigned long long), m->stream));
+        launch_map_units(ix->d, b, m->grid_blocks, m->want_stats, m->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(m->ev[2], m->stream));
+        HIP_TRY(hipMemcpyAsync(&ids, b.ids_cursor, sizeof(ids), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if ((int64_t)ids <= b.ids_capacity) break;
+        if (attempt == 2) return fail(SKM_ERR_STATE, "entry arena overflow");
+        SKM_TRY(m->unit_entries.ensure((size_t)ids + 1024));
+    }
+    m->last_ids = (int64_t)ids;
+    if (m->want_stats) {
+        unsigned long long st[16];
+        HIP_TRY(hipMemcpy(st, b.stats, sizeof(st), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; ++i) m->stats_total[i] += st[i];
+        m->stats_total[9] += ids;
+    }
+
+    // class counting
+    SKM_TRY(table_reserve(m, n_units));
+    SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)ids + 1024), true, m->stream));
+    bind_table(m, m->t.slot_mask + 1);
+    launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, m->stream);
+    launch_class_verify_commit(m->t, b, m->units_done, m->unit_slot.p, m->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev[3], m->stream));
+    unsigned long long ctr[4];
+    HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
+    SKM_TRY(read_error(m));
+    m->host_arena_used = (int64_t)ctr[CTR_ARENA];
+    m->host_classes = (int64_t)ctr[CTR_CLASSES];
+    m->units_done += n_units;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->t_pack_ns += ms * 1e6;
+    HIP_TRY(hipEventElapsedTime(&ms, m->ev[1], m->ev[2])); m->t_map_ns += ms * 1e6;
+    HIP_TRY(hipEventElapsedTime(&ms, m->ev[2], m->ev[3])); m->t_class_ns += ms * 1e6;
+    m->batches += 1;
+    return SKM_OK;
+}
+
+}  // namespace
+
+extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
+{
+    if (!ix || !out) return fail(SKM_ERR_ARG, "NULL argument");
+    SKM_TRY(set_device(ix->device));
+    skm_mapper *m = new skm_mapper();
+    m->ix = ix;
+    HIP_TRY(hipStreamCreate(&m->stream));
+    for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
+    m->want_stats = getenv("SKM_MAP_STATS") != nullptr;
+    int rc = table_reset(m, 1 << 16);
+    if (rc != SKM_OK) { delete m; return rc; }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    *out = m;
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_destroy(skm_mapper *m)
+{
+    if (!m) return SKM_OK;
+    (void)hipSetDevice(m->ix->device);
+    (void)hipStreamSynchronize(m->stream);
+    m->slots.release(); m->arena_len.release(); m->arena.release(); m->counters.release();
+    m->error.release(); m->bases.release(); m->offsets.release(); m->codes.release();
+    m->acgt.release(); m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
+    m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
+    m->unit_slot.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
+    for (auto &e : m->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(m->stream);
+    delete m;
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_map_batch(skm_mapper *m, const char *bases, const int64_t *offsets,
+                                    int64_t n_units, int paired)
+{
+    if (!m || !offsets || n_units < 0) return fail(SKM_ERR_ARG, "bad argument");
+    if (n_units > 0 && !bases) return fail(SKM_ERR_ARG, "bases is NULL");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    const int64_t n_reads = paired ? 2 * n_units : n_units;
+    int64_t max_len = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const int64_t len = offsets[r + 1] - offsets[r];
+        if (len < 0) return fail(SKM_ERR_ARG, "offsets are not monotone at read %lld", (long long)r);
+        max_len = std::max(max_len, len);
+    }
+    if (max_len > (1 << 20)) return fail(SKM_ERR_ARG, "read longer than 2^20 bases");
+    const int64_t n_bytes = offsets[n_reads] - offsets[0];
+    SKM_TRY(m->bases.ensure((size_t)n_bytes + 64));
+    SKM_TRY(m->offsets.ensure((size_t)n_reads + 1));
+    std::vector<int64_t> rel;
+    const int64_t *src_off = offsets;
+    if (offsets[0] != 0) {
+        rel.resize(n_reads + 1);
+        for (int64_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - offsets[0];
+        src_off = rel.data();
+    }
+    if (n_bytes)
+        HIP_TRY(hipMemcpyAsync(m->bases.p, bases + offsets[0], (size_t)n_bytes, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->offsets.p, src_off, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return map_batch_resident(m, m->bases.p, m->offsets.p, n_units, paired, (int)max_len);
+}
+
+extern "C" int skm_mapper_map_batch_device(skm_mapper *m, const void *d_bases, const void *d_offsets,
+                                           int64_t n_units, int paired, int32_t max_read_len)
+{
+    if (!m || !d_offsets || n_units < 0 || max_read_len < 0)
+        return fail(SKM_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    return map_batch_resident(m, (const uint8_t *)d_bases, (const int64_t *)d_offsets, n_units,
+                              paired, max_read_len);
+}
+
+extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end,
+                                     int32_t *anchor_entry, int32_t *anchor_offset, int32_t *counts,
+                                     int32_t *entries, int64_t cap_entries, int64_t *n_entries)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    const int64_t n = m->last_units;
+    if (n_entries) *n_entries = m->last_ids;
+    if (n == 0) return SKM_OK;
+    if (begin) HIP_TRY(hipMemcpy(begin, m->unit_begin.p, n * 4, hipMemcpyDeviceToHost));
+    if (end) HIP_TRY(hipMemcpy(end, m->unit_end.p, n * 4, hipMemcpyDeviceToHost));
+    if (anchor_entry || anchor_offset) {
+        std::vector<Coord> a(n);
+        HIP_TRY(hipMemcpy(a.data(), m->unit_anchor.p, n * sizeof(Coord), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) {
+            if (anchor_entry) anchor_entry[i] = a[i].entry;
+            if (anchor_offset) anchor_offset[i] = a[i].offset;
+        }
+    }
+    std::vector<int32_t> cnt;
+    if (counts || entries) {
+        cnt.resize(n);
+        HIP_TRY(hipMemcpy(cnt.data(), m->unit_count.p, n * 4, hipMemcpyDeviceToHost));
+        if (counts) memcpy(counts, cnt.data(), n * 4);
+    }
+    if (entries) {
+        std::vector<int64_t> off(n);
+        std::vector<int32_t> raw((size_t)std::max<int64_t>(m->last_ids, 1));
+        HIP_TRY(hipMemcpy(off.data(), m->unit_offset.p, n * 8, hipMemcpyDeviceToHost));
+        if (m->last_ids)
+            HIP_TRY(hipMemcpy(raw.data(), m->unit_entries.p, (size_t)m->last_ids * 4, hipMemcpyDeviceToHost));
+        int64_t pos = 0;
+        for (int64_t u = 0; u < n; ++u) {
+            for (int i = 0; i < cnt[u]; ++i)
+                if (pos + i < cap_entries) entries[pos + i] = raw[off[u] + i];
+            pos += cnt[u];
+        }
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_summary(skm_mapper *m, int64_t summary[4])
+{
+    if (!m || !summary) return fail(SKM_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    unsigned long long ctr[4];
+    HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));
+    summary[0] = (int64_t)ctr[CTR_CLASSES];
+    summary[1] = (int64_t)ctr[CTR_ARENA];
+    summary[2] = (int64_t)ctr[CTR_UNALIGNED];
+    summary[3] = (int64_t)ctr[CTR_UNITS];
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_export(skm_mapper *m, int64_t *class_offsets, int32_t *class_targets,
+                                 int64_t *class_counts, int64_t *first_seen, int64_t *fld)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    if (fld)
+        HIP_TRY(hipMemcpy(fld, m->counters.p + CTR_FLD, MAX_FRAGMENT_LENGTH * 8, hipMemcpyDeviceToHost));
+    if (!class_offsets && !class_targets && !class_counts && !first_seen) return SKM_OK;
+    const int64_t C = m->host_classes, M = m->host_arena_used;
+    if (class_offsets) class_offsets[0] = 0;
+    if (C == 0) return SKM_OK;
+    DBuf<int64_t> d_off; DBuf<int32_t> d_len; DBuf<double> d_cnt; DBuf<unsigned long long> d_fs, d_cur;
+    SKM_TRY(d_off.ensure(C)); SKM_TRY(d_len.ensure(C)); SKM_TRY(d_cnt.ensure(C));
+    SKM_TRY(d_fs.ensure(C)); SKM_TRY(d_cur.ensure(1));
+    HIP_TRY(hipMemsetAsync(d_cur.p, 0, 8, m->stream));
+    launch_class_compact(m->t, d_off.p, d_len.p, d_cnt.p, d_fs.p, d_cur.p, m->stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<int64_t> off(C);
+    std::vector<int32_t> len(C);
+    std::vector<double> cnt(C);
+    std::vector<unsigned long long> fs(C);
+    std::vector<int32_t> arena((size_t)std::max<int64_t>(M, 1));
+    HIP_TRY(hipMemcpyAsync(off.data(), d_off.p, C * 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(len.data(), d_len.p, C * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt.p, C * 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(fs.data(), d_fs.p, C * 8, hipMemcpyDeviceToHost, m->stream));
+    if (M) HIP_TRY(hipMemcpyAsync(arena.data(), m->arena.p, (size_t)M * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    d_off.release(); d_len.release(); d_cnt.release(); d_fs.release(); d_cur.release();
+    // Counter insertion order under -j1 = ascending first-seen unit (mapper.py:88)
+    std::vector<int64_t> order(C);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return fs[a] < fs[b]; });
+    int64_t pos = 0;
+    for (int64_t k = 0; k < C; ++k) {
+        const int64_t c = order[k];
+        if (class_targets)
+            memcpy(class_targets + pos, arena.data() + off[c], (size_t)len[c] * 4);
+        pos += len[c];
+        if (class_offsets) class_offsets[k + 1] = pos;
+        if (class_counts) class_counts[k] = (int64_t)cnt[c];
+        if (first_seen) first_seen[k] = (int64_t)fs[c];
+    }
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t *class_offsets,
+                                const int32_t *class_targets, const int64_t *class_counts,
+                                const int64_t *first_seen, int64_t unaligned, const int64_t *fld)
+{
+    if (!m || n_classes < 0 || unaligned < 0) return fail(SKM_ERR_ARG, "bad argument");
+    if (n_classes && (!class_offsets || !class_targets || !class_counts || !first_seen))
+        return fail(SKM_ERR_ARG, "NULL class arrays");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    std::vector<unsigned long long> add(CTR_WORDS, 0);
+    int64_t units = unaligned;
+    for (int64_t c = 0; c < n_classes; ++c) units += class_counts[c];
+    add[CTR_UNALIGNED] = (unsigned long long)unaligned;
+    add[CTR_UNITS] = (unsigned long long)units;
+    if (fld) for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) add[CTR_FLD + i] = (unsigned long long)fld[i];
+    std::vector<unsigned long long> cur(CTR_WORDS);
+    HIP_TRY(hipMemcpy(cur.data(), m->counters.p, CTR_WORDS * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < CTR_WORDS; ++i) cur[i] += add[i];
+    HIP_TRY(hipMemcpy(m->counters.p, cur.data(), CTR_WORDS * 8, hipMemcpyHostToDevice));
+    if (n_classes) {
+        const int64_t M = class_offsets[n_classes];
+        SKM_TRY(table_reserve(m, n_classes));
+        SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + M + 1024), true, m->stream));
+        bind_table(m, m->t.slot_mask + 1);
+        DBuf<int64_t> d_off, d_cnt, d_fs; DBuf<int32_t> d_ids;
+        SKM_TRY(d_off.ensure(n_classes + 1)); SKM_TRY(d_cnt.ensure(n_classes));
+        SKM_TRY(d_fs.ensure(n_classes)); SKM_TRY(d_ids.ensure(std::max<int64_t>(M, 1)));
+        HIP_TRY(hipMemcpy(d_off.p, class_offsets, (n_classes + 1) * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_cnt.p, class_counts, n_classes * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_fs.p, first_seen, n_classes * 8, hipMemcpyHostToDevice));
+        if (M) HIP_TRY(hipMemcpy(d_ids.p, class_targets, M * 4, hipMemcpyHostToDevice));
+        launch_class_merge(m->t, n_classes, d_off.p, d_ids.p, d_cnt.p, d_fs.p, m->stream);
+        HIP_TRY(hipGetLastError());
+        unsigned long long ctr[4];
+        HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
+        int rc = read_error(m);
+        d_off.release(); d_cnt.release(); d_fs.release(); d_ids.release();
+        if (rc != SKM_OK) return rc;
+        m->host_arena_used = (int64_t)ctr[CTR_ARENA];
+        m->host_classes = (int64_t)ctr[CTR_CLASSES];
+    }
+    m->units_done += units;
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_clear(skm_mapper *m)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    // MapResult.clear only clears the counter (mapper.py:143-145): the FLD stays
+    std::vector<unsigned long long> fld(MAX_FRAGMENT_LENGTH);
+    HIP_TRY(hipMemcpy(fld.data(), m->counters.p + CTR_FLD, MAX_FRAGMENT_LENGTH * 8, hipMemcpyDeviceToHost));
+    SKM_TRY(table_reset(m, m->t.slot_mask + 1));
+    HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_FLD, fld.data(), MAX_FRAGMENT_LENGTH * 8, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
+{
+    if (!m || !stats) return fail(SKM_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    stats[0] = m->t_pack_ns; stats[1] = m->t_map_ns; stats[2] = m->t_class_ns;
+    stats[3] = m->batches; stats[4] = (double)m->units_done;
+    stats[5] = 0; stats[6] = 0; stats[7] = 0;
+    return SKM_OK;
+}
+
+// access counters of the STATS build of the map kernel (SKM_MAP_STATS=1):
+// [0]=reads [1]=read bases [2]=lookups [3]=slots [4]=contig reads [5]=targets
+// copied [6]=targets merged [7]=8-base fetches [8]=merges [9]=tuple ids
+extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[16])
+{
+    if (!m || !out) return fail(SKM_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    for (int i = 0; i < 16; ++i) out[i] = (int64_t)m->stats_total[i];
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_set_stats(skm_mapper *m, int enable)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    std::lock_guard<std::mutex> lock(m->mu);
+    m->want_stats = enable != 0;
+    return SKM_OK;
+}
+
+// ------------------------------------------------------------ quantification
+extern "C" int skm_effective_lengths(int device, const int64_t *fld, const double *lengths,
+                                     int64_t n_tx, double *out)
+{
+    if (!fld || !lengths || !out || n_tx < 0) return fail(SKM_ERR_ARG, "bad argument");
+    int n_dev = 0;
+    SKM_TRY(skm_device_count(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(SKM_ERR_ARG, "device %d out of range", device);
+    SKM_TRY(set_device(device));
+    if (n_tx == 0) return SKM_OK;
+    DBuf<unsigned long long> d_fld; DBuf<double> d_len, d_out;
+    SKM_TRY(d_fld.ensure(MAX_FRAGMENT_LENGTH)); SKM_TRY(d_len.ensure(n_tx)); SKM_TRY(d_out.ensure(n_tx));
+    HIP_TRY(hipMemcpy(d_fld.p, fld, MAX_FRAGMENT_LENGTH * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_len.p, lengths, n_tx * 8, hipMemcpyHostToDevice));
+    launch_effective_lengths(d_fld.p, d_len.p, n_tx, d_out.p, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, n_tx * 8, hipMemcpyDeviceToHost));
+    d_fld.release(); d_len.release(); d_out.release();
+    return SKM_OK;
+}
+
+namespace {
+
+int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64_t n_ids)
+{
+    q->device = device;
+    q->n_tx = n_tx;
+    q->n_classes = n_classes;
+    q->n_ids = n_ids;
+    HIP_TRY(hipStreamCreate(&q->stream));
+    for (auto &e : q->ev) HIP_TRY(hipEventCreate(&e));
+    SKM_TRY(q->cls_offset.ensure(std::max<int64_t>(n_classes, 1)));
+    SKM_TRY(q->cls_len.ensure(std::max<int64_t>(n_classes, 1)));
+    SKM_TRY(q->cls_count.ensure(std::max<int64_t>(n_classes, 1)));
+    SKM_TRY(q->ids.ensure(std::max<int64_t>(n_ids, 1)));
+    SKM_TRY(q->eff_len.ensure(std::max<int64_t>(n_tx, 1)));
+    SKM_TRY(q->x0.ensure(std::max<int64_t>(n_tx, 1)));
+    SKM_TRY(q->x1.ensure(std::max<int64_t>(n_tx, 1)));
+    SKM_TRY(q->acc.ensure(std::max<int64_t>(n_tx, 1)));
+    SKM_TRY(q->ctl.ensure(16));
+    return SKM_OK;
+}
+
+// ---- RCCL through dlopen: the library is only needed for N > 1
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+struct UniqueId { char internal[128]; };
+typedef int (*comm_init_fn)(void **, int, UniqueId, int);
+Rccl g_rccl;
+comm_init_fn g_comm_init = nullptr;
+
+int load_rccl()
+{
+    if (g_rccl.lib) return SKM_OK;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(SKM_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+    g_comm_init = (comm_init_fn)dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_comm_init || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(SKM_ERR_COMM, "librccl.so lacks a required symbol");
+    g_rccl.lib = lib;
+    return SKM_OK;
+}
+
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+
+#define NCCL_TRY(call)                                                                   \
+    do {                                                                                 \
+        int r_ = (call);                                                                 \
+        if (r_ != 0)                                                                     \
+            return fail(SKM_ERR_COMM, "%s failed: %s", #call,                            \
+                        g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");        \
+    } while (0)
+
+EmProblem em_problem(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters,
+                     int64_t fixed_iters)
+{
+    EmProblem p{};
+    p.n_tx = q->n_tx;
+    p.n_classes = q->n_classes;
+    p.cls_offset = q->cls_offset.p;
+    p.cls_len = q->cls_len.p;
+    p.ids = q->ids.p;
+    p.cls_count = q->cls_count.p;
+    p.eff_len = q->eff_len.p;
+    p.x[0] = q->x0.p;
+    p.x[1] = q->x1.p;
+    p.acc = q->acc.p;
+    p.n_total = q->n_total;
+    p.rel_tol = rel_tol;
+    p.x_floor = x_floor;
+    p.ctl = q->ctl.p;
+    p.max_iters = max_iters;
+    p.fixed_iters = fixed_iters;
+    return p;
+}
+
+// runs the EM from the abundance already in q->x0; result left in x[iters & 1]
+int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int64_t fixed_iters,
+           int64_t *iters_out)
+{
+    // n = class_count.sum() over ALL ranks (infer.py:152)
+    double n_total = q->n_total;
+    if (q->comm) {
+        HIP_TRY(hipMemcpyAsync(q->acc.p, &n_total, 8, hipMemcpyHostToDevice, q->stream));
+        NCCL_TRY(g_rccl.AllReduce(q->acc.p, q->acc.p, 1, NCCL_FLOAT64, NCCL_SUM, q->comm, q->stream));
+        HIP_TRY(hipMemcpyAsync(&n_total, q->acc.p, 8, hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+    }
+    EmProblem p = em_problem(q, rel_tol, x_floor, max_iters, fixed_iters);
+    p.n_total = n_total;
+    HIP_TRY(hipMemsetAsync(q->acc.p, 0, (size_t)std::max<int64_t>(q->n_tx, 1) * 8, q->stream));
+    HIP_TRY(hipMemsetAsync(q->ctl.p, 0, 16 * 8, q->stream));
+    unsigned long long ctl[8] = {0};
+    int64_t k = 0;
+    const int64_t chunk = fixed_iters > 0 ? std::min<int64_t>(fixed_iters, 16) : 8;
+    HIP_TRY(hipEventRecord(q->ev[0], q->stream));
+    for (;;) {
+        for (int64_t i = 0; i < chunk; ++i, ++k) {
+            launch_em_scatter(p, (int)(k & 1), q->stream);
+            if (q->comm)
+                NCCL_TRY(g_rccl.AllReduce(q->acc.p, q->acc.p, (size_t)q->n_tx, NCCL_FLOAT64, NCCL_SUM,
+                                          q->comm, q->stream));
+            launch_em_finalize(p, (int)(k & 1), q->stream);
+            q->launches += 2;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(ctl, q->ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+        if (ctl[0]) break;
+    }
+    HIP_TRY(hipEventRecord(q->ev[1], q->stream));
+    HIP_TRY(hipEventSynchronize(q->ev[1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, q->ev[0], q->ev[1]));
+    q->t_em_ns += ms * 1e6;
+    q->iters_total += (double)ctl[1];
+    if (iters_out) *iters_out = (int64_t)ctl[1];
+    if (ctl[6]) return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
+    return SKM_OK;
+}
+
+}  // namespace
+
+extern "C" int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
+                                const int64_t *class_offsets, const int32_t *class_targets,
+                                const double *class_counts, skm_quant **out)
+{
+    if (!out || n_tx <= 0 || n_classes < 0) return fail(SKM_ERR_ARG, "bad argument");
+    if (n_classes && (!class_offsets || !class_targets || !class_counts))
+        return fail(SKM_ERR_ARG, "NULL class arrays");
+    int n_dev = 0;
+    SKM_TRY(skm_device_count(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(SKM_ERR_ARG, "device %d out of range", device);
+    const int64_t M = n_classes ? class_offsets[n_classes] : 0;
+    std::vector<int32_t> len(std::max<int64_t>(n_classes, 1));
+    double total = 0;
+    for (int64_t c = 0; c < n_classes; ++c) {
+        const int64_t l = class_offsets[c + 1] - class_offsets[c];
+        if (l < 0 || l > INT32_MAX) return fail(SKM_ERR_ARG, "class offsets are not monotone");
+        len[c] = (int32_t)l;
+        total += class_counts[c];
+    }
+    for (int64_t j = 0; j < M; ++j)
+        if (class_targets[j] < 0 || class_targets[j] >= n_tx)
+            return fail(SKM_ERR_ARG, "class target %d outside [0, n_tx)", class_targets[j]);
+    SKM_TRY(set_device(device));
+    skm_quant *q = new skm_quant();
+    int rc = quant_alloc(q, device, n_tx, n_classes, M);
+    if (rc != SKM_OK) { delete q; return rc; }
+    if (n_classes) {
+        HIP_TRY(hipMemcpy(q->cls_offset.p, class_offsets, n_classes * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(q->cls_len.p, len.data(), n_classes * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(q->cls_count.p, class_counts, n_classes * 8, hipMemcpyHostToDevice));
+        if (M) HIP_TRY(hipMemcpy(q->ids.p, class_targets, M * 4, hipMemcpyHostToDevice));
+    }
+    q->n_total = total;
+    *out = q;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_create_from_mapper(skm_mapper *m, int64_t n_tx, skm_quant **out)
+{
+    if (!m || !out || n_tx <= 0) return fail(SKM_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    const int64_t C = m->host_classes, M = m->host_arena_used;
+    skm_quant *q = new skm_quant();
+    int rc = quant_alloc(q, m->ix->device, n_tx, C, M);
+    if (rc != SKM_OK) { delete q; return rc; }
+    unsigned long long ctr[4];
+    HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));
+    q->n_total = (double)(ctr[CTR_UNITS] - ctr[CTR_UNALIGNED]);
+    if (C) {
+        DBuf<unsigned long long> cur;
+        SKM_TRY(cur.ensure(1));
+        HIP_TRY(hipMemsetAsync(cur.p, 0, 8, m->stream));
+        launch_class_compact(m->t, q->cls_offset.p, q->cls_len.p, q->cls_count.p, nullptr, cur.p, m->stream);
+        HIP_TRY(hipGetLastError());
+        if (M) HIP_TRY(hipMemcpyAsync(q->ids.p, m->arena.p, (size_t)M * 4, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        cur.release();
+    }
+    *out = q;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_destroy(skm_quant *q)
+{
+    if (!q) return SKM_OK;
+    (void)hipSetDevice(q->device);
+    if (q->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(q->comm);
+    (void)hipStreamSynchronize(q->stream);
+    q->cls_offset.release(); q->cls_len.release(); q->ids.release(); q->cls_count.release();
+    q->cls_count_saved.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
+    q->acc.release(); q->ctl.release(); q->cum.release(); q->draw.release();
+    for (auto &e : q->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(q->stream);
+    delete q;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_em(skm_quant *q, double *x, const double *l, double rel_tol, double x_floor,
+                            int64_t max_iters, int64_t fixed_iters, int64_t *iters)
+{
+    if (!q || !x || !l) return fail(SKM_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    SKM_TRY(set_device(q->device));
+    HIP_TRY(hipMemcpyAsync(q->x0.p, x, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(hipMemcpyAsync(q->eff_len.p, l, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
+    int64_t it = 0;
+    SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, fixed_iters, &it));
+    HIP_TRY(hipMemcpy(x, (it & 1) ? q->x1.p : q->x0.p, q->n_tx * 8, hipMemcpyDeviceToHost));
+    if (iters) *iters = it;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_set_counts(skm_quant *q, const double *class_counts)
+{
+    if (!q || (!class_counts && q->n_classes)) return fail(SKM_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    SKM_TRY(set_device(q->device));
+    double total = 0;
+    for (int64_t c = 0; c < q->n_classes; ++c) total += class_counts[c];
+    if (q->n_classes)
+        HIP_TRY(hipMemcpy(q->cls_count.p, class_counts, q->n_classes * 8, hipMemcpyHostToDevice));
+    q->n_total = total;
+    q->have_cum = false;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0,
+                                   const double *l, double rel_tol, double x_floor, int64_t max_iters,
+                                   double *out, int64_t *counts_out, int64_t *iters_out)
+{
+    if (!q || !x0 || !l || !out || n_boot < 0) return fail(SKM_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    SKM_TRY(set_device(q->device));
+    const int64_t C = q->n_classes;
+    if (C == 0) return fail(SKM_ERR_STATE, "no classes to resample");
+    // integer cumulative counts of the observed table
+    SKM_TRY(q->cls_count_saved.ensure(C));
+    SKM_TRY(q->cum.ensure(C));
+    SKM_TRY(q->draw.ensure(C));
+    HIP_TRY(hipMemcpyAsync(q->cls_count_saved.p, q->cls_count.p, C * 8, hipMemcpyDeviceToDevice, q->stream));
+    std::vector<double> cnt(C);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), q->cls_count.p, C * 8, hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    std::vector<unsigned long long> cum(C);
+    unsigned long long run = 0;
+    for (int64_t c = 0; c < C; ++c) { run += (unsigned long long)cnt[c]; cum[c] = run; }
+    HIP_TRY(hipMemcpyAsync(q->cum.p, cum.data(), C * 8, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(hipMemcpyAsync(q->eff_len.p, l, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
+    const double saved_total = q->n_total;
+    const int64_t n_draws = (int64_t)run;            // n = class_count.sum(), infer.py:109
+    int rc = SKM_OK;
+    for (int64_t b = 0; b < n_boot && rc == SKM_OK; ++b) {
+        HIP_TRY(hipMemsetAsync(q->draw.p, 0, C * 8, q->stream));
+        launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)b + (uint64_t)q->rank * 0x100000000ULL,
+                           q->draw.p, q->stream);
+        launch_u64_to_double(q->draw.p, C, q->cls_count.p, q->stream);
+        HIP_TRY(hipGetLastError());
+        if (counts_out) {
+            static_assert(sizeof(unsigned long long) == sizeof(int64_t), "");
+            HIP_TRY(hipMemcpyAsync(counts_out + b * C, q->draw.p, C * 8, hipMemcpyDeviceToHost, q->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(q->x0.p, x0, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
+        q->n_total = (double)n_draws;
+        int64_t it = 0;
+        rc = em_run(q, rel_tol, x_floor, max_iters, 0, &it);
+        if (rc != SKM_OK) break;
+        HIP_TRY(hipMemcpy(out + b * q->n_tx, (it & 1) ? q->x1.p : q->x0.p, q->n_tx * 8, hipMemcpyDeviceToHost));
+        if (iters_out) iters_out[b] = it;
+    }
+    HIP_TRY(hipMemcpyAsync(q->cls_count.p, q->cls_count_saved.p, C * 8, hipMemcpyDeviceToDevice, q->stream));
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    q->n_total = saved_total;
+    return rc;
+}
+
+extern "C" int skm_quant_timing(skm_quant *q, double timing[4])
+{
+    if (!q || !timing) return fail(SKM_ERR_ARG, "NULL argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    timing[0] = q->t_em_ns; timing[1] = q->iters_total; timing[2] = q->launches; timing[3] = 0;
+    return SKM_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU
+extern "C" int skm_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(SKM_ERR_ARG, "NULL argument");
+    SKM_TRY(load_rccl());
+    NCCL_TRY(g_rccl.GetUniqueId(id128));
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_comm_init(skm_quant *q, const void *id128, int rank, int world)
+{
+    if (!q || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SKM_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(q->mu);
+    SKM_TRY(set_device(q->device));
+    SKM_TRY(load_rccl());
+    UniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCL_TRY(g_comm_init(&q->comm, world, id, rank));
+    q->rank = rank;
+    q->world = world;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_comm_destroy(skm_quant *q)
+{
+    if (!q) return SKM_OK;
+    std::lock_guard<std::mutex> lock(q->mu);
+    if (q->comm && g_rccl.CommDestroy) NCCL_TRY(g_rccl.CommDestroy(q->comm));
+    q->comm = nullptr;
+    q->world = 1;
+    return SKM_OK;
+}

@@ -1,0 +1,260 @@
+// GPU-resident equivalence-class counter: the device replacement of
+// MapResult.counter (collections.Counter keyed by the id tuple,
+// /root/reference/seekmer/mapper.py:54, 60-70) and of the class enumeration
+// in MapResult.summarize (mapper.py:85-92).
+//
+// Open-addressing table keyed by a 64-bit tag of the tuple.  A batch is
+// counted in three launches so that no lane ever spins on another lane:
+//   insert  -- claim or find the slot by tag (atomicCAS), count++ and
+//              first_seen = min(global unit index)            (integer atomics)
+//   verify  -- every unit compares its FULL tuple with the class
+//              representative (the committed arena copy, or, for a class born
+//              in this batch, the unit that holds first_seen); a mismatch is a
+//              64-bit tag collision and raises SKM_ERR_COLLISION, so counts are
+//              exact or the call fails -- never silently merged
+//   commit  -- the representative of each new class copies its tuple into the
+//              arena
+// Launch boundaries provide all inter-workgroup ordering; within a launch only
+// device-scope atomics touch shared words.
+#include "skm_kernels.h"
+#include "../../include/seekmer_hip.h"
+
+namespace skm {
+
+__device__ __forceinline__ uint32_t unsigned_id(int32_t e) { return (uint32_t)(e < 0 ? ~e : e); }
+
+__global__ void __launch_bounds__(256)
+class_init_kernel(ClassSlot *slots, int32_t *arena_len, uint64_t n_slots)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_slots;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        slots[i].key = 0;
+        slots[i].count = 0;
+        slots[i].first_seen = ~0ULL;
+        slots[i].arena_offset = -1;
+        arena_len[i] = 0;
+    }
+}
+
+// find-or-claim the slot whose tag is `key`; returns the slot index
+__device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned long long key,
+                                                bool &claimed)
+{
+    uint64_t slot = key & t.slot_mask;
+    claimed = false;
+    for (uint64_t n = 0; n <= t.slot_mask; ++n) {
+        unsigned long long cur = __hip_atomic_load(&t.slots[slot].key, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            cur = atomicCAS(&t.slots[slot].key, 0ULL, key);
+            if (cur == 0) { claimed = true; return slot; }
+        }
+        if (cur == key) return slot;
+        slot = (slot + 1) & t.slot_mask;
+    }
+    return ~0ULL;    // table full (the host grows it long before)
+}
+
+__global__ void __launch_bounds__(256)
+class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot)
+{
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = b.unit_key[u];
+        if (key == 0) {                       // empty tuple = unaligned, mapper.py:87
+            atomicAdd(t.n_unaligned, 1ULL);
+            unit_slot[u] = -1;
+            continue;
+        }
+        bool claimed;
+        const uint64_t slot = probe_claim(t, key, claimed);
+        if (slot == ~0ULL) { atomicExch(t.error, SKM_ERR_STATE); unit_slot[u] = -1; continue; }
+        if (claimed) atomicAdd(t.n_classes, 1ULL);
+        atomicAdd(&t.slots[slot].count, 1ULL);
+        atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
+        unit_slot[u] = (int64_t)slot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(t.n_units, (unsigned long long)b.n_units);
+}
+
+__global__ void __launch_bounds__(256)
+class_verify_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *unit_slot)
+{
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = unit_slot[u];
+        if (slot < 0) continue;
+        const int n = b.unit_count[u];
+        const int32_t *mine = b.unit_entries + b.unit_offset[u];
+        const long long committed = t.slots[slot].arena_offset;
+        bool same = true;
+        if (committed >= 0) {
+            same = t.arena_len[slot] == n;
+            const int32_t *ref = t.arena + committed;
+            for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
+        } else {
+            const int64_t rep = (int64_t)t.slots[slot].first_seen - unit_base;
+            if (rep < 0 || rep >= b.n_units) { atomicExch(t.error, SKM_ERR_STATE); continue; }
+            if (rep != u) {
+                same = b.unit_count[rep] == n;
+                const int32_t *ref = b.unit_entries + b.unit_offset[rep];
+                for (int i = 0; same && i < n; ++i) same = unsigned_id(ref[i]) == unsigned_id(mine[i]);
+            }
+        }
+        if (!same) atomicExch(t.error, SKM_ERR_COLLISION);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+class_commit_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *unit_slot)
+{
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = unit_slot[u];
+        if (slot < 0) continue;
+        if (t.slots[slot].arena_offset >= 0) continue;
+        if ((int64_t)t.slots[slot].first_seen - unit_base != u) continue;
+        const int n = b.unit_count[u];
+        const long long off = (long long)atomicAdd(t.arena_cursor, (unsigned long long)n);
+        if (off + n > t.arena_capacity) { atomicExch(t.error, SKM_ERR_STATE); continue; }
+        const int32_t *mine = b.unit_entries + b.unit_offset[u];
+        for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(mine[i]);
+        t.arena_len[slot] = n;
+        t.slots[slot].arena_offset = off;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_FRAGMENT_LENGTH;
+         i += gridDim.x * blockDim.x) {
+        t.global_fld[i] += b.fld[i];     // merge_fragment_lengths, mapper.py:106-115
+    }
+}
+
+// move every class of `from` into the (larger, initialised) table `to`
+__global__ void __launch_bounds__(256)
+class_rehash_kernel(ClassTable from, ClassTable to)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= from.slot_mask;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const ClassSlot s = from.slots[i];
+        if (s.key == 0) continue;
+        bool claimed;
+        const uint64_t slot = probe_claim(to, s.key, claimed);
+        if (slot == ~0ULL || !claimed) { atomicExch(to.error, SKM_ERR_STATE); continue; }
+        to.slots[slot].count = s.count;
+        to.slots[slot].first_seen = s.first_seen;
+        to.slots[slot].arena_offset = s.arena_offset;
+        to.arena_len[slot] = from.arena_len[i];
+    }
+}
+
+// dense list of classes for the EM: arena offset, tuple length, count as f8
+__global__ void __launch_bounds__(256)
+class_compact_kernel(ClassTable t, int64_t *cls_offset, int32_t *cls_len, double *cls_count,
+                     unsigned long long *cls_first_seen, unsigned long long *cursor)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= t.slot_mask;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const ClassSlot s = t.slots[i];
+        if (s.key == 0) continue;
+        const unsigned long long k = atomicAdd(cursor, 1ULL);
+        cls_offset[k] = s.arena_offset;
+        cls_len[k] = t.arena_len[i];
+        cls_count[k] = (double)s.count;
+        if (cls_first_seen) cls_first_seen[k] = s.first_seen;
+    }
+}
+
+// Counter.update with a foreign table (another GPU's export)
+__global__ void __launch_bounds__(256)
+class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets,
+                   const int32_t *class_targets, const int64_t *class_counts,
+                   const int64_t *first_seen)
+{
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_classes;
+         c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t off = class_offsets[c];
+        const int n = (int)(class_offsets[c + 1] - off);
+        unsigned long long key = 0x243F6A8885A308D3ULL ^ (unsigned long long)n;
+        for (int i = 0; i < n; ++i) {
+            key ^= (uint32_t)class_targets[off + i];
+            key *= 0x9E3779B97F4A7C15ULL;
+            key ^= key >> 32;
+        }
+        if (key == 0) key = 1;
+        bool claimed;
+        const uint64_t slot = probe_claim(t, key, claimed);
+        if (slot == ~0ULL) { atomicExch(t.error, SKM_ERR_STATE); continue; }
+        if (claimed) {
+            const long long a = (long long)atomicAdd(t.arena_cursor, (unsigned long long)n);
+            if (a + n > t.arena_capacity) { atomicExch(t.error, SKM_ERR_STATE); continue; }
+            for (int i = 0; i < n; ++i) t.arena[a + i] = class_targets[off + i];
+            t.arena_len[slot] = n;
+            t.slots[slot].arena_offset = a;
+            atomicAdd(t.n_classes, 1ULL);
+        } else {
+            // classes of the resident table are all committed between batches
+            const long long a = t.slots[slot].arena_offset;
+            bool same = a >= 0 && t.arena_len[slot] == n;
+            for (int i = 0; same && i < n; ++i) same = t.arena[a + i] == class_targets[off + i];
+            if (!same) { atomicExch(t.error, SKM_ERR_COLLISION); continue; }
+        }
+        atomicAdd(&t.slots[slot].count, (unsigned long long)class_counts[c]);
+        atomicMin(&t.slots[slot].first_seen, (unsigned long long)first_seen[c]);
+    }
+}
+
+static inline unsigned grid_for(int64_t n)
+{
+    int64_t blocks = (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (unsigned)blocks;
+}
+
+void launch_class_init(const ClassTable &t, hipStream_t stream)
+{
+    hipLaunchKernelGGL(class_init_kernel, dim3(grid_for((int64_t)t.slot_mask + 1)), dim3(256), 0,
+                       stream, t.slots, t.arena_len, t.slot_mask + 1);
+}
+
+void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
+                         int64_t *unit_slot, hipStream_t stream)
+{
+    if (b.n_units == 0) return;
+    hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
+                       unit_base, unit_slot);
+}
+
+void launch_class_verify_commit(const ClassTable &t, const MapBatch &b, int64_t unit_base,
+                                const int64_t *unit_slot, hipStream_t stream)
+{
+    if (b.n_units == 0) return;
+    hipLaunchKernelGGL(class_verify_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
+                       unit_base, unit_slot);
+    hipLaunchKernelGGL(class_commit_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
+                       unit_base, unit_slot);
+}
+
+void launch_class_rehash(const ClassTable &from, const ClassTable &to, hipStream_t stream)
+{
+    hipLaunchKernelGGL(class_rehash_kernel, dim3(grid_for((int64_t)from.slot_mask + 1)), dim3(256),
+                       0, stream, from, to);
+}
+
+void launch_class_compact(const ClassTable &t, int64_t *cls_offset, int32_t *cls_len,
+                          double *cls_count, unsigned long long *cls_first_seen,
+                          unsigned long long *cursor, hipStream_t stream)
+{
+    hipLaunchKernelGGL(class_compact_kernel, dim3(grid_for((int64_t)t.slot_mask + 1)), dim3(256), 0,
+                       stream, t, cls_offset, cls_len, cls_count, cls_first_seen, cursor);
+}
+
+void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *class_offsets,
+                        const int32_t *class_targets, const int64_t *class_counts,
+                        const int64_t *first_seen, hipStream_t stream)
+{
+    if (n_classes == 0) return;
+    hipLaunchKernelGGL(class_merge_kernel, dim3(grid_for(n_classes)), dim3(256), 0, stream, t,
+                       n_classes, class_offsets, class_targets, class_counts, first_seen);
+}
+
+}  // namespace skm

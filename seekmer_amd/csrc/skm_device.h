@@ -1,0 +1,200 @@
+// Device-side primitives shared by the gfx950 kernels: k-mer arithmetic, the
+// reference's SipHash variant, index probing and packed-read access.
+// Semantics follow /root/reference/seekmer/_kmer.pxd, _coordinate.pxd and the
+// query half of _common.pyx (cited per function); the code is written for
+// CDNA4 (64-wide waves, one unit per lane), not translated from the Cython.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace skm {
+
+constexpr int K = 25;                               // _kmer.pxd:9-17
+constexpr uint64_t KMER_MASK = (1ULL << 50) - 1;    // _kmer.pxd:31-39
+constexpr uint64_t KMER_INVALID = ~0ULL;            // _kmer.pxd:20-28
+constexpr int MAX_FRAGMENT_LENGTH = 2000;           // _mapper.pyx:18
+constexpr int ALIGN_LENGTH = 8;                     // _mapper.pyx:22
+constexpr int MAX_OFFSET = 2;                       // _mapper.pyx:24
+constexpr int MAX_DISTANCE = 4;                     // _mapper.pyx:26
+constexpr int INVALID_SHIFT = 0x7FFF;               // _mapper.pyx:28
+
+struct Coord { int32_t entry; int32_t offset; };                 // _coordinate.pxd:8-10
+struct alignas(16) IndexEntry { uint64_t kmer; Coord pos; };     // _common.pxd:15-17
+struct ContigEntry {                                             // _common.pxd:21-27
+    int64_t offset, length;
+    uint64_t first_kmer, last_kmer;
+    int64_t target_offset, target_length;
+};
+
+// Index as it lives in HBM.  kmers/contigs/targets keep the reference's array
+// layout; the pooled contig bases are re-packed to 2 bits (32 bases per u64,
+// first base in the top bits) because the mapper only ever needs 8-base
+// windows of them.
+struct DevIndex {
+    const IndexEntry *kmers;
+    uint32_t slot_mask;
+    const ContigEntry *contigs;
+    int64_t n_contigs;
+    const uint64_t *seq2;      // 2-bit packed pooled bases, one zero pad word
+    int64_t n_bases;
+    const Coord *targets;
+    int64_t n_targets;
+    int32_t max_target_count;
+};
+
+__device__ __forceinline__ Coord invalid_coord() { return Coord{0, -1}; }  // _coordinate.pxd:13-24
+
+// _kmer.pxd:146-171: reverse the 2-bit groups of the 64-bit word, shift the
+// 50 payload bits down, complement.
+__device__ __forceinline__ uint64_t kmer_revcomp(uint64_t k)
+{
+    k = ((k >> 2) & 0x3333333333333333ULL) | ((k & 0x3333333333333333ULL) << 2);
+    k = ((k >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((k & 0x0f0f0f0f0f0f0f0fULL) << 4);
+    k = __builtin_bswap64(k);
+    k >>= (64 - 2 * K);
+    return ~k & KMER_MASK;
+}
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int s) { return (x << s) | (x >> (64 - s)); }
+
+#define SKM_SIP_HALF(a, b, c, d, s, t) \
+    do { a += b; c += d; b = rotl64(b, s) ^ a; d = rotl64(d, t) ^ c; a = rotl64(a, 32); } while (0)
+#define SKM_SIP_ROUND(v0, v1, v2, v3) \
+    do { SKM_SIP_HALF(v0, v1, v2, v3, 13, 16); SKM_SIP_HALF(v2, v1, v0, v3, 17, 21); } while (0)
+
+// _kmer.pxd:174-219: SipHash-2-4 of one 8-byte word under the fixed key
+// (5381, 42) with the reference's non-standard tail (v0 ^= 0 after the length
+// block) and truncation to 32 bits.
+__device__ __forceinline__ uint32_t kmer_hash(uint64_t kmer)
+{
+    uint64_t v0 = 5381ULL ^ 0x736f6d6570736575ULL;
+    uint64_t v1 = 42ULL ^ 0x646f72616e646f6dULL;
+    uint64_t v2 = 5381ULL ^ 0x6c7967656e657261ULL;
+    uint64_t v3 = 42ULL ^ 0x7465646279746573ULL;
+    v3 ^= kmer;
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    v0 ^= kmer;
+    v3 ^= (8ULL << 56);
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    v2 ^= 0xff;
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    SKM_SIP_ROUND(v0, v1, v2, v3);
+    return (uint32_t)((v0 ^ v1) ^ (v2 ^ v3));
+}
+
+// _kmer.pxd:253-273
+__device__ __forceinline__ uint32_t two_bit_encode(uint32_t c)
+{
+    c &= 0xDFu;                       // fold case (only used on letters below)
+    return c == 'T' ? 3u : c == 'G' ? 2u : c == 'C' ? 1u : 0u;
+}
+
+// per-lane access counters (only in the STATS instantiation of the map kernel)
+struct LaneStats {
+    uint32_t lookups, slots, contig_reads, targets_copied, targets_merged,
+             seq_fetches, merges;
+};
+
+// KMerIndex.map_kmer, _common.pyx:54-97.  Home slot = hash(min(kmer, rc)) &
+// (size-1); linear probe with wrap-around; empty slot ends the probe.
+template <bool STATS>
+__device__ __forceinline__ Coord map_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
+{
+    const uint64_t rc = kmer_revcomp(kmer);
+    uint32_t slot = kmer_hash(kmer < rc ? kmer : rc) & ix.slot_mask;
+    if (STATS) st->lookups++;
+    for (uint32_t n = 0; n <= ix.slot_mask; ++n) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(&ix.kmers[slot]);
+        const uint64_t stored = ((uint64_t)raw.y << 32) | raw.x;
+        if (STATS) st->slots++;
+        if (stored == KMER_INVALID) return invalid_coord();
+        if (stored == kmer) return Coord{(int32_t)raw.z, (int32_t)raw.w};
+        if (stored == rc) return Coord{~(int32_t)raw.z, (int32_t)raw.w};
+        slot = (slot + 1) & ix.slot_mask;
+    }
+    return invalid_coord();
+}
+
+// 32 consecutive 2-bit codes starting at base `p` of a packed array (first
+// base in the top bits).  The arrays carry one pad word, so w+1 is readable.
+__device__ __forceinline__ uint64_t packed_window(const uint64_t *words, int64_t p)
+{
+    const int64_t w = p >> 5;
+    const int s = (int)(p & 31) << 1;
+    const uint64_t hi = words[w];
+    if (s == 0) return hi;
+    return (hi << s) | (words[w + 1] >> (64 - s));
+}
+
+// reverse-complement of 8 packed bases (16 bits)
+__device__ __forceinline__ uint32_t revcomp8(uint32_t v)
+{
+    v = ((v >> 2) & 0x3333u) | ((v & 0x3333u) << 2);
+    v = ((v >> 4) & 0x0f0fu) | ((v & 0x0f0fu) << 4);
+    v = ((v >> 8) & 0x00ffu) | ((v & 0x00ffu) << 8);
+    return ~v & 0xffffu;
+}
+
+// KMerIndex.get_contig_sequence for |length| == 8, _common.pyx:103-137:
+// leading (length>0) or trailing (length<0) 8 bases of the anchored k-mer in
+// read orientation, as 16 bits (first base on top).  The pool index is
+// clamped so that an inconsistent index can never fault the GPU.
+template <bool STATS>
+__device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, bool leading, LaneStats *st)
+{
+    int32_t index = c.entry < 0 ? ~c.entry : c.entry;
+    int64_t offset = ix.contigs[index].offset + c.offset;
+    if (STATS) { st->contig_reads++; st->seq_fetches++; }
+    if (c.entry >= 0) offset += leading ? ALIGN_LENGTH : K;
+    else offset += leading ? K : ALIGN_LENGTH;
+    int64_t first = offset - ALIGN_LENGTH;
+    if (first < 0) first = 0;
+    if (first > ix.n_bases - ALIGN_LENGTH) first = ix.n_bases - ALIGN_LENGTH;
+    uint32_t v = (uint32_t)(packed_window(ix.seq2, first) >> 48);
+    if (c.entry < 0) v = revcomp8(v);
+    return v;
+}
+
+// KMerIndex.get_tail_kmer, _common.pyx:241-266
+template <bool STATS>
+__device__ __forceinline__ uint64_t tail_kmer(const DevIndex &ix, Coord c, LaneStats *st)
+{
+    int32_t index = c.entry < 0 ? ~c.entry : c.entry;
+    if (STATS) st->contig_reads++;
+    uint64_t k = c.offset == 0 ? ix.contigs[index].first_kmer : ix.contigs[index].last_kmer;
+    if (c.entry < 0) k = kmer_revcomp(k);
+    return k;
+}
+
+// A read in packed form: 2-bit codes (N and everything else that is not
+// ACGT/acgt encode as 0, _kmer.pxd:253-273) plus one bit per base that says
+// "is upper-case ACGT" -- the only property _match_base needs
+// (_mapper.pyx:500-501).
+struct ReadView {
+    const uint64_t *codes;
+    const uint32_t *acgt;     // 32 bases per word, first base in the top bit
+    int len;
+};
+
+__device__ __forceinline__ uint64_t read_kmer(const ReadView &r, int p)      // _kmer.pxd:46-68
+{
+    return packed_window(r.codes, p) >> (64 - 2 * K);
+}
+__device__ __forceinline__ uint32_t read_code(const ReadView &r, int p)
+{
+    return (uint32_t)(r.codes[p >> 5] >> (62 - 2 * (p & 31))) & 3u;
+}
+// 16 bases of codes (32 bits) and 16 "is ACGT" bits starting at base p
+__device__ __forceinline__ void read_window16(const ReadView &r, int p, uint32_t &codes, uint32_t &acgt)
+{
+    codes = (uint32_t)(packed_window(r.codes, p) >> 32);
+    const int w = p >> 5, s = p & 31;
+    uint64_t m = ((uint64_t)r.acgt[w] << 32) | r.acgt[w + 1];
+    acgt = (uint32_t)((m << s) >> 48);
+}
+
+}  // namespace skm

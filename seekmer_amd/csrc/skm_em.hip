@@ -1,0 +1,257 @@
+// Quantification kernels for gfx950: effective lengths, the EM step, the
+// multinomial bootstrap draw.  They replace the numpy loop of
+// /root/reference/seekmer/infer.py:133-168 (em), mapper.py:134-141
+// (effective_lengths) and the scipy draw of infer.py:108-111.
+//
+// One EM step is two launches on one stream:
+//   em_scatter  -- one lane per class: S_c = sum of x over the tuple (in tuple
+//                  order, as numpy.bincount accumulates it), inner_c = S_c /
+//                  count_c, then x_t / inner_c is scatter-added into acc[t]
+//                  with f64 memory-side atomics
+//   em_finalize -- one lane per transcript: x'_t = acc_t / l_t / n, NaN -> 0,
+//                  relative change against x_t, block max -> atomicMax; the
+//                  last block to finish evaluates the reference's stopping rule
+//                  and latches `done`, after which every later launch of the
+//                  chunk is a no-op (so the host can enqueue steps in chunks
+//                  and still stop at exactly the reference's iteration count).
+// The step is HBM/L2-bound integer-indexed gather + scatter: no MFMA.
+#include "skm_kernels.h"
+
+namespace skm {
+
+enum { CTL_DONE = 0, CTL_ITERS = 1, CTL_TICKET = 2, CTL_MAX = 3, CTL_ANY = 4, CTL_NAN = 5,
+       CTL_UNDEFINED = 6 };
+
+__global__ void __launch_bounds__(256)
+em_scatter_kernel(EmProblem p, int parity)
+{
+    if (p.ctl[CTL_DONE]) return;
+    const double *__restrict__ x = p.x[parity];
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < p.n_classes;
+         c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t off = p.cls_offset[c];
+        const int len = p.cls_len[c];
+        double s = 0.0;
+        for (int j = 0; j < len; ++j) s += x[p.ids[off + j]];
+        const double inner = s / p.cls_count[c];                 // infer.py:155-156
+        for (int j = 0; j < len; ++j) {
+            const int32_t t = p.ids[off + j];
+            atomicAdd(&p.acc[t], x[t] / inner);                  // infer.py:157
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+em_finalize_kernel(EmProblem p, int parity)
+{
+    if (p.ctl[CTL_DONE]) return;
+    const double *__restrict__ x_old = p.x[parity];
+    double *__restrict__ x_new = p.x[parity ^ 1];
+    double local_max = 0.0;
+    int any = 0, nan = 0;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < p.n_tx;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        double v = p.acc[t] / p.eff_len[t] / p.n_total;          // infer.py:158
+        if (v != v) v = 0.0;                                     // infer.py:159
+        p.acc[t] = 0.0;
+        x_new[t] = v;
+        if (v > p.x_floor) {                                     // infer.py:160
+            const double r = fabs(v - x_old[t]) / v;
+            if (r != r) nan = 1;
+            else if (r > local_max) local_max = r;
+            any = 1;
+        }
+    }
+    // wave reduce, then one set of atomics per wave
+    for (int d = 32; d > 0; d >>= 1) {
+        const double o = __shfl_xor(local_max, d, 64);
+        local_max = o > local_max ? o : local_max;
+        any |= __shfl_xor(any, d, 64);
+        nan |= __shfl_xor(nan, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (any) {
+            atomicMax(&p.ctl[CTL_MAX], (unsigned long long)__double_as_longlong(local_max));
+            atomicOr(&p.ctl[CTL_ANY], 1ULL);
+        }
+        if (nan) atomicOr(&p.ctl[CTL_NAN], 1ULL);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = atomicAdd(&p.ctl[CTL_TICKET], 1ULL);
+        if (ticket == gridDim.x - 1) {
+            // last block: all other blocks' atomics are complete (memory-side RMWs)
+            const unsigned long long max_bits = atomicAdd(&p.ctl[CTL_MAX], 0ULL);
+            const unsigned long long any_f = atomicAdd(&p.ctl[CTL_ANY], 0ULL);
+            const unsigned long long nan_f = atomicAdd(&p.ctl[CTL_NAN], 0ULL);
+            const unsigned long long iters = p.ctl[CTL_ITERS] + 1;
+            bool done;
+            if (p.fixed_iters > 0) {
+                done = (int64_t)iters >= p.fixed_iters;
+            } else if (!any_f) {
+                p.ctl[CTL_UNDEFINED] = 1;     // numpy raises on max() of an empty selection
+                done = true;
+            } else {
+                const double m = __longlong_as_double((long long)max_bits);
+                done = nan_f || !(m > p.rel_tol);
+                if (p.max_iters > 0 && (int64_t)iters >= p.max_iters) done = true;
+            }
+            p.ctl[CTL_ITERS] = iters;
+            p.ctl[CTL_TICKET] = 0;
+            p.ctl[CTL_MAX] = 0;
+            p.ctl[CTL_ANY] = 0;
+            p.ctl[CTL_NAN] = 0;
+            __threadfence();
+            p.ctl[CTL_DONE] = done ? 1ULL : 0ULL;
+        }
+    }
+}
+
+// MapResult.effective_lengths, mapper.py:134-141: p = fld / fld.sum();
+// eff_t = sum_i max(len_t - i, 1) * p_i accumulated for i = 0..1999 in order
+// (compiled with -ffp-contract=off: separate multiply and add, as numpy).
+__global__ void __launch_bounds__(256)
+effective_lengths_kernel(const unsigned long long *__restrict__ fld,
+                         const double *__restrict__ lengths, int64_t n_tx, double *__restrict__ out)
+{
+    __shared__ double p[MAX_FRAGMENT_LENGTH];
+    __shared__ unsigned long long total_s;
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) total += fld[i];
+        total_s = total;
+    }
+    __syncthreads();
+    const double total = (double)(long long)total_s;
+    for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x)
+        p[i] = (double)(long long)fld[i] / total;
+    __syncthreads();
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_tx;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const double len = lengths[t];
+        double acc = 0.0;
+        for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) {
+            double v = len - (double)i;
+            if (v < 1.0) v = 1.0;
+            acc += v * p[i];
+        }
+        out[t] = acc;
+    }
+}
+
+// Counter-based generator for the bootstrap draw (the reference draws from
+// numpy's unseeded global generator, so only the distribution can be matched).
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// multinomial(n, count / n) as n categorical draws over the integer
+// cumulative counts: r uniform in [0, n), class = first c with cum[c] > r.
+__global__ void __launch_bounds__(256)
+multinomial_kernel(const unsigned long long *__restrict__ cum, int64_t n_classes, int64_t n_draws,
+                   uint64_t seed, uint64_t stream_id, unsigned long long *__restrict__ counts)
+{
+    const unsigned long long total = cum[n_classes - 1];
+    for (int64_t d = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; d < n_draws;
+         d += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t bits = mix64(mix64(seed ^ (stream_id * 0x9E3779B97F4A7C15ULL)) + (uint64_t)d
+                                    * 0xD1342543DE82EF95ULL);
+        const unsigned long long r = __umul64hi(bits, total);
+        int64_t lo = 0, hi = n_classes - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cum[mid] > r) hi = mid; else lo = mid + 1;
+        }
+        atomicAdd(&counts[lo], 1ULL);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+u64_to_double_kernel(const unsigned long long *__restrict__ in, int64_t n, double *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i];
+}
+
+__global__ void __launch_bounds__(256)
+double_to_cum_u64_kernel(const double *__restrict__ in, int64_t n, unsigned long long *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (unsigned long long)in[i];
+}
+
+// ASCII pooled contig bases -> 2-bit words (first base in the top bits)
+__global__ void __launch_bounds__(256)
+pack_sequences_kernel(const char *__restrict__ bases, int64_t n_bases, uint64_t *__restrict__ seq2,
+                      int64_t n_words)
+{
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n_words;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t c = 0;
+        const int64_t first = w * 32;
+        for (int i = 0; i < 32 && first + i < n_bases; ++i)
+            c |= (uint64_t)two_bit_encode((uint8_t)bases[first + i]) << (62 - 2 * i);
+        seq2[w] = c;
+    }
+}
+
+static inline unsigned grid_for(int64_t n, int64_t cap = 256 * 16)
+{
+    int64_t blocks = (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)blocks;
+}
+
+void launch_em_scatter(const EmProblem &p, int parity, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_scatter_kernel, dim3(grid_for(p.n_classes)), dim3(256), 0, stream, p, parity);
+}
+
+void launch_em_finalize(const EmProblem &p, int parity, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_finalize_kernel, dim3(grid_for(p.n_tx, 1024)), dim3(256), 0, stream, p, parity);
+}
+
+void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
+                              double *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(effective_lengths_kernel, dim3(grid_for(n_tx)), dim3(256), 0, stream, fld,
+                       lengths, n_tx, out);
+}
+
+void launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_t n_draws,
+                        uint64_t seed, uint64_t stream_id, unsigned long long *counts,
+                        hipStream_t stream)
+{
+    if (n_draws <= 0 || n_classes <= 0) return;
+    hipLaunchKernelGGL(multinomial_kernel, dim3(grid_for(n_draws)), dim3(256), 0, stream, cum,
+                       n_classes, n_draws, seed, stream_id, counts);
+}
+
+void launch_u64_to_double(const unsigned long long *in, int64_t n, double *out, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(u64_to_double_kernel, dim3(grid_for(n)), dim3(256), 0, stream, in, n, out);
+}
+
+void launch_double_to_u64(const double *in, int64_t n, unsigned long long *out, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(double_to_cum_u64_kernel, dim3(grid_for(n)), dim3(256), 0, stream, in, n, out);
+}
+
+void launch_pack_sequences(const char *bases, int64_t n_bases, uint64_t *seq2, int64_t n_words,
+                           hipStream_t stream)
+{
+    hipLaunchKernelGGL(pack_sequences_kernel, dim3(grid_for(n_words)), dim3(256), 0, stream, bases,
+                       n_bases, seq2, n_words);
+}
+
+}  // namespace skm
