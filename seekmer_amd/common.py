@@ -1,0 +1,297 @@
+"""Index container and FASTQ feeders -- the `seekmer.common` surface
+(reference: seekmer/common.py:1-197, seekmer/_common.pyx:19-313) over the
+MI355X engine.
+
+``KMerIndex`` keeps the reference's six public numpy attributes with the
+reference's dtypes and lazily uploads the four mapping
+arrays to HBM through the C ABI.  ``load``/``save`` use a flat ``.npz``
+container: the reference's HDF5 layout needs PyTables, which this image lacks
+(abundance.h5 / index HDF5 parity: unpinned).
+"""
+import bz2
+import contextlib
+import ctypes
+import gzip
+import io
+import lzma
+import pathlib
+import subprocess
+import threading
+
+import numpy
+
+from . import _native
+
+__all__ = ('INVALID_INDEX', 'BUFFER_SIZE', 'decompress_and_open', 'read_fasta',
+           'iterate_by_group', 'KMerIndex', 'feed_single_ended_reads',
+           'feed_pair_ended_reads', 'NativeReadFeeder', 'ReadBatch')
+
+INVALID_INDEX = 0x7FFFFFFF          # seekmer/_common.pxd:10
+BUFFER_SIZE = 65536                 # seekmer/common.py:16
+
+KMER_DTYPE = numpy.dtype([('kmer', '<u8'), ('entry', '<i4'), ('offset', '<i4')])
+CONTIG_DTYPE = numpy.dtype([('offset', '<i8'), ('length', '<i8'), ('first_kmer', '<u8'),
+                            ('last_kmer', '<u8'), ('target_offset', '<i8'),
+                            ('target_count', '<i8')])
+TARGET_DTYPE = numpy.dtype([('entry', '<i4'), ('offset', '<i4')])
+
+_INDEX_VERSION = '2019.0.0'         # seekmer/_common.pyx:278
+
+
+class KMerIndex:
+    """The core index (seekmer/_common.pyx:19-48)."""
+
+    def __init__(self, kmers, contigs, sequences, targets, transcripts, exons):
+        self.kmers = numpy.ascontiguousarray(kmers)
+        self.contigs = numpy.ascontiguousarray(contigs)
+        self.sequences = numpy.ascontiguousarray(sequences)
+        self.targets = numpy.ascontiguousarray(targets)
+        self.transcripts = transcripts
+        self.exons = exons
+        if self.kmers.dtype.itemsize != 16 or self.contigs.dtype.itemsize != 48 \
+                or self.targets.dtype.itemsize != 8 or self.sequences.dtype.itemsize != 1:
+            raise ValueError('index arrays do not have the KMerIndex layout')
+        self._handles = {}
+        self._lock = threading.Lock()
+
+    # -- device residency -------------------------------------------------
+    def device_handle(self, device=0):
+        """Opaque skm_index* for `device`, created on first use."""
+        with self._lock:
+            handle = self._handles.get(device)
+            if handle is None:
+                out = ctypes.c_void_p()
+                _native.check(_native.hip().skm_index_create(
+                    self.kmers.ctypes.data, self.kmers.size,
+                    self.contigs.ctypes.data, self.contigs.size,
+                    self.sequences.ctypes.data, self.sequences.size,
+                    self.targets.ctypes.data, self.targets.size,
+                    device, ctypes.byref(out)))
+                handle = out
+                self._handles[device] = handle
+            return handle
+
+    def release(self):
+        with self._lock:
+            for handle in self._handles.values():
+                _native.hip().skm_index_destroy(handle)
+            self._handles.clear()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # -- persistence --------------------------------------------------------
+    def save(self, path):
+        """Save the index (flat .npz container, see module docstring)."""
+        with open(str(path), 'wb') as f:
+            numpy.savez(f, seekmer_version=numpy.asarray(_INDEX_VERSION),
+                        kmers=self.kmers, contigs=self.contigs, sequences=self.sequences,
+                        targets=self.targets, transcripts=numpy.asarray(self.transcripts),
+                        exons=numpy.asarray(self.exons))
+
+    @classmethod
+    def load(cls, path):
+        """Load an index written by :meth:`save`."""
+        with numpy.load(str(path), allow_pickle=False) as data:
+            if str(data['seekmer_version']) != _INDEX_VERSION:
+                raise RuntimeError('invalid index version.')     # seekmer/_common.pyx:303-304
+            return cls(data['kmers'], data['contigs'], data['sequences'], data['targets'],
+                       data['transcripts'], data['exons'])
+
+
+# ------------------------------------------------------------------ file input
+@contextlib.contextmanager
+def decompress_and_open(path):
+    """Open `path` for binary reading, decompressing by suffix
+    (seekmer/common.py:23-75: external zcat/bzcat/xzcat first, stdlib second)."""
+    path = pathlib.Path(path)
+    tools = {'.gz': ('zcat', gzip), '.bz2': ('bzcat', bz2), '.xz': ('xzcat', lzma),
+             '.lzma': ('xzcat', lzma)}
+    if path.suffix in tools:
+        tool, module = tools[path.suffix]
+        try:
+            process = subprocess.Popen([tool, str(path)], stdout=subprocess.PIPE)
+        except OSError:
+            process = None
+        if process is not None:
+            with process:
+                yield process.stdout
+        else:
+            with module.open(str(path), 'rb') as raw, io.BufferedReader(raw) as f:
+                yield f
+    else:
+        with path.open('rb') as f:
+            yield f
+
+
+def read_fasta(path):
+    """Yield (name, sequence) of a FASTA file (seekmer/common.py:78-105)."""
+    name = None
+    chunks = []
+    with decompress_and_open(path) as file:
+        for line in file:
+            if line[0] != ord(b'>'):
+                chunks.append(line.strip())
+                continue
+            if name is not None:
+                yield name, b''.join(chunks)
+            name = line[1:].strip()
+            chunks = []
+        if name is not None:
+            yield name, b''.join(chunks)
+
+
+def iterate_by_group(iterator, group_size):
+    """Groups of `group_size` consecutive items (seekmer/common.py:108-123)."""
+    return zip(*([iter(iterator)] * group_size))
+
+
+def feed_single_ended_reads(*paths):
+    """Yield (count, names, reads) batches (seekmer/common.py:126-158)."""
+    names, reads = [], []
+    for path in paths:
+        with decompress_and_open(path) as file:
+            for i, line in enumerate(file):
+                phase = i & 3
+                if phase == 0:
+                    names.append(line.strip()[1:])
+                elif phase == 1:
+                    reads.append(line.strip())
+                    if len(names) >= BUFFER_SIZE:
+                        yield len(names), names, reads
+                        names, reads = [], []
+    if reads:
+        yield len(names), names, reads
+
+
+def feed_pair_ended_reads(*paths):
+    """Yield (count, names, interleaved mates) batches (seekmer/common.py:161-197)."""
+    if len(paths) % 2 != 0:
+        raise ValueError('cannot process odd numbers of pair-ended files')
+    names, reads = [], []
+    for path1, path2 in iterate_by_group(paths, 2):
+        with decompress_and_open(path1) as file1, decompress_and_open(path2) as file2:
+            for i, (line1, line2) in enumerate(zip(file1, file2)):
+                phase = i & 3
+                if phase == 0:
+                    names.append(line1.strip()[1:])
+                elif phase == 1:
+                    reads.append(line1.strip())
+                    reads.append(line2.strip())
+                    if len(names) >= BUFFER_SIZE:
+                        yield len(names), names, reads
+                        names, reads = [], []
+    if reads:
+        yield len(names), names, reads
+
+
+# ----------------------------------------------------------- native batch feed
+class ReadBatch:
+    """A batch in the flat layout the C ABI takes: `bases` (uint8, reads back
+    to back) and `offsets` (int64[n_reads + 1]).  Unpacks like the reference's
+    (count, names, reads) triple, so code written against the feeders works."""
+
+    __slots__ = ('count', 'bases', 'offsets', 'paired', '_names', '_name_offsets')
+
+    def __init__(self, count, bases, offsets, paired, names=None, name_offsets=None):
+        self.count = int(count)
+        self.bases = bases
+        self.offsets = offsets
+        self.paired = bool(paired)
+        self._names = names
+        self._name_offsets = name_offsets
+
+    @property
+    def names(self):
+        if self._names is None:
+            return [b''] * self.count
+        raw = self._names.tobytes()
+        o = self._name_offsets
+        return [raw[o[i]:o[i + 1]] for i in range(self.count)]
+
+    @property
+    def reads(self):
+        raw = self.bases.tobytes()
+        o = self.offsets
+        return [raw[o[i]:o[i + 1]] for i in range(o.size - 1)]
+
+    def __iter__(self):
+        return iter((self.count, self.names, self.reads))
+
+    @classmethod
+    def from_lists(cls, count, names, reads):
+        """Pack the reference's triple (paired iff len(reads) == 2 * count,
+        seekmer/_mapper.pyx:73-75)."""
+        offsets = numpy.zeros(len(reads) + 1, dtype=numpy.int64)
+        numpy.cumsum([len(r) for r in reads], out=offsets[1:])
+        bases = numpy.frombuffer(b''.join(reads) + b'\0', dtype=numpy.uint8)
+        batch = cls(count, bases, offsets, count != len(reads))
+        if names is not None:
+            name_offsets = numpy.zeros(len(names) + 1, dtype=numpy.int64)
+            numpy.cumsum([len(n) for n in names], out=name_offsets[1:])
+            batch._names = numpy.frombuffer(b''.join(names) + b'\0', dtype=numpy.uint8)
+            batch._name_offsets = name_offsets
+        return batch
+
+
+class NativeReadFeeder:
+    """FASTQ batches from the native reader (skm_fastq_*): the same batching
+    rule as the feeders above, without per-read Python objects.  Compressed
+    inputs are piped through zcat/bzcat/xzcat as the reference does."""
+
+    def __init__(self, paths, paired, batch_units=BUFFER_SIZE):
+        paths = [pathlib.Path(p) for p in paths]
+        if paired and len(paths) % 2 != 0:
+            raise ValueError('cannot process odd numbers of pair-ended files')
+        self.paths = paths
+        self.paired = bool(paired)
+        self.batch_units = int(batch_units)
+
+    def __iter__(self):
+        tools = {'.gz': 'zcat', '.bz2': 'bzcat', '.xz': 'xzcat', '.lzma': 'xzcat'}
+        processes, names = [], []
+        try:
+            for path in self.paths:
+                if path.suffix in tools:
+                    process = subprocess.Popen([tools[path.suffix], str(path)],
+                                               stdout=subprocess.PIPE)
+                    processes.append(process)
+                    names.append(('/dev/fd/%d' % process.stdout.fileno()).encode())
+                else:
+                    names.append(str(path).encode())
+            array = (ctypes.c_char_p * len(names))(*names)
+            reader = ctypes.c_void_p()
+            _native.check_host(_native.host().skm_fastq_open(
+                array, len(names), int(self.paired), self.batch_units, ctypes.byref(reader)),
+                'skm_fastq_open')
+            try:
+                n = ctypes.c_int64()
+                p_bases, p_off = ctypes.c_void_p(), ctypes.c_void_p()
+                p_names, p_noff = ctypes.c_void_p(), ctypes.c_void_p()
+                while True:
+                    _native.check_host(_native.host().skm_fastq_next(
+                        reader, ctypes.byref(n), ctypes.byref(p_bases), ctypes.byref(p_off),
+                        ctypes.byref(p_names), ctypes.byref(p_noff)), 'skm_fastq_next')
+                    if n.value == 0:
+                        break
+                    n_reads = n.value * (2 if self.paired else 1)
+                    offsets = numpy.ctypeslib.as_array(
+                        ctypes.cast(p_off, _native.c_i64p), (n_reads + 1,)).copy()
+                    bases = numpy.ctypeslib.as_array(
+                        ctypes.cast(p_bases, ctypes.POINTER(ctypes.c_uint8)),
+                        (int(offsets[-1]) + 1,)).copy()
+                    name_offsets = numpy.ctypeslib.as_array(
+                        ctypes.cast(p_noff, _native.c_i64p), (n.value + 1,)).copy()
+                    name_bytes = numpy.ctypeslib.as_array(
+                        ctypes.cast(p_names, ctypes.POINTER(ctypes.c_uint8)),
+                        (max(int(name_offsets[-1]), 1),)).copy()
+                    yield ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets)
+            finally:
+                _native.host().skm_fastq_close(reader)
+        finally:
+            for process in processes:
+                process.stdout.close()
+                process.wait()

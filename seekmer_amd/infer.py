@@ -1,0 +1,321 @@
+"""Abundance inference -- the `seekmer.infer` surface (reference:
+seekmer/infer.py:1-353) over the MI355X engine: `run`, `quantify`, `em`,
+`output_results`, `add_subcommand_parser` keep their signatures; the EM loop
+and the bootstrap resampling run as HIP kernels behind the C ABI.
+"""
+import ctypes
+import datetime
+import json
+import logging
+import pathlib
+import shlex
+import sys
+
+import numpy
+
+from . import _native
+from . import common
+from . import mapper
+
+__all__ = ['run', 'quantify', 'em', 'output_results', 'bootstrap_quantify']
+
+_LOG = logging.getLogger(__name__)
+
+REL_TOL = 0.01          # seekmer/infer.py:160
+X_FLOOR = 1e-8          # seekmer/infer.py:160
+
+
+def run(index_path, output_path, fastq_paths, job_count, save_readmap,
+        single_ended, bootstrap, debug, device=0, seed=None, **__):
+    """The entrypoint of the inference module (seekmer/infer.py:27-85)."""
+    start_time = datetime.datetime.utcnow()
+    try:
+        output_path.mkdir(parents=True)
+    except FileExistsError:
+        _LOG.warning('The output folder exists. Overriding...')
+    readmap = (output_path / 'readmap.txt').open('wt') if save_readmap else None
+    _LOG.info('Inferring transcript abundance')
+    index = common.KMerIndex.load(index_path)
+    _LOG.info('Mapping all reads')
+    read_feeder = common.NativeReadFeeder(fastq_paths, paired=not single_ended)
+    map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
+                                  readmap=readmap, debug=debug, device=device)
+    _LOG.info('Mapped all reads')
+    _LOG.info('Estimated fragment length: %.2f', map_result.harmonic_mean_fragment_length)
+    summarized_results = map_result.summarize()
+    _LOG.info('Quantifying transcripts')
+    _LOG.info('Aligned %d reads (%.2f%%)', summarized_results.aligned,
+              100.0 * summarized_results.aligned / summarized_results.total)
+    main_result = quantify(summarized_results)
+    _LOG.info('Quantified transcripts')
+    bootstrapped_results = bootstrap_quantify(summarized_results, main_result, bootstrap,
+                                              seed=seed)
+    output_results(output_path, index, start_time, summarized_results,
+                   main_result, bootstrapped_results)
+    _LOG.info('Wrote results to %s', output_path)
+
+
+# ------------------------------------------------------------- device tables
+class _QuantHandle:
+    """skm_quant* for one class table."""
+
+    def __init__(self, handle, n_tx, n_classes):
+        self.handle = handle
+        self.n_tx = n_tx
+        self.n_classes = n_classes
+
+    @classmethod
+    def from_csr(cls, n_tx, offsets, targets, counts, device=0):
+        offsets = numpy.ascontiguousarray(offsets, dtype=numpy.int64)
+        targets = numpy.ascontiguousarray(targets if len(targets) else [0], dtype=numpy.int32)
+        counts = numpy.ascontiguousarray(counts if len(counts) else [0.0], dtype='f8')
+        out = ctypes.c_void_p()
+        _native.check(_native.hip().skm_quant_create(
+            device, n_tx, offsets.size - 1, _native.ptr(offsets, _native.c_i64p),
+            _native.ptr(targets, _native.c_i32p), _native.ptr(counts, _native.c_f64p),
+            ctypes.byref(out)))
+        return cls(out, n_tx, offsets.size - 1)
+
+    @classmethod
+    def from_map_result(cls, map_result, n_tx):
+        out = ctypes.c_void_p()
+        _native.check(_native.hip().skm_quant_create_from_mapper(
+            map_result._handle, n_tx, ctypes.byref(out)))
+        return cls(out, n_tx, map_result.sizes()[0])
+
+    def em(self, x, l, fixed_iters=0, max_iters=0):
+        x = numpy.array(x, dtype='f8', copy=True, order='C')
+        l = numpy.ascontiguousarray(l, dtype='f8')
+        iters = ctypes.c_int64()
+        _native.check(_native.hip().skm_quant_em(
+            self.handle, _native.ptr(x, _native.c_f64p), _native.ptr(l, _native.c_f64p),
+            REL_TOL, X_FLOOR, max_iters, fixed_iters, ctypes.byref(iters)))
+        return x, iters.value
+
+    def set_counts(self, counts):
+        counts = numpy.ascontiguousarray(counts, dtype='f8')
+        _native.check(_native.hip().skm_quant_set_counts(self.handle,
+                                                         _native.ptr(counts, _native.c_f64p)))
+
+    def bootstrap(self, n_boot, seed, x0, l, want_counts=False):
+        x0 = numpy.ascontiguousarray(x0, dtype='f8')
+        l = numpy.ascontiguousarray(l, dtype='f8')
+        out = numpy.zeros((n_boot, self.n_tx), dtype='f8')
+        counts = numpy.zeros((n_boot, max(self.n_classes, 1)), dtype=numpy.int64) if want_counts else None
+        iters = numpy.zeros(max(n_boot, 1), dtype=numpy.int64)
+        _native.check(_native.hip().skm_quant_bootstrap(
+            self.handle, n_boot, seed, _native.ptr(x0, _native.c_f64p),
+            _native.ptr(l, _native.c_f64p), REL_TOL, X_FLOOR, 0,
+            _native.ptr(out, _native.c_f64p),
+            _native.ptr(counts, _native.c_i64p) if want_counts else None,
+            _native.ptr(iters, _native.c_i64p)))
+        return out, counts, iters[:n_boot]
+
+    def timing(self):
+        out = (ctypes.c_double * 4)()
+        _native.check(_native.hip().skm_quant_timing(self.handle, out))
+        return {'em_ns': out[0], 'iterations': int(out[1]), 'launches': int(out[2])}
+
+    def close(self):
+        if self.handle:
+            _native.hip().skm_quant_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _csr_from_class_map(class_map, n_classes):
+    """class_map int64[2, M] (seekmer/mapper.py:93) -> CSR keeping the pair
+    order inside every class."""
+    class_ids = numpy.asarray(class_map[0], dtype=numpy.int64)
+    targets = numpy.asarray(class_map[1], dtype=numpy.int64)
+    if class_ids.size > 1 and (numpy.diff(class_ids) < 0).any():
+        order = numpy.argsort(class_ids, kind='stable')
+        class_ids, targets = class_ids[order], targets[order]
+    offsets = numpy.zeros(n_classes + 1, dtype=numpy.int64)
+    numpy.cumsum(numpy.bincount(class_ids, minlength=n_classes), out=offsets[1:])
+    return offsets, targets.astype(numpy.int32)
+
+
+def _tpm(x):
+    """seekmer/infer.py:127-129"""
+    x /= x.sum() / 1000000
+    x[x < 0.001] = 0
+    x /= x.sum() / 1000000
+    return x
+
+
+def _quant_for(results, device=0):
+    cached = getattr(results, '_quant', None) if hasattr(results, '__dict__') else None
+    if cached is not None:
+        return cached, False
+    n_tx = results.effective_lengths.size
+    offsets = getattr(results, 'class_offsets', None)
+    targets = getattr(results, 'class_targets', None)
+    if offsets is None or targets is None:
+        offsets, targets = _csr_from_class_map(results.class_map, results.class_count.size)
+    return _QuantHandle.from_csr(n_tx, offsets, targets, results.class_count, device), True
+
+
+def quantify(results, x0=None, bootstrap=False, seed=None, fixed_iters=0, return_iters=False):
+    """Estimate the transcript abundance (seekmer/infer.py:88-130)."""
+    transcript_length = results.effective_lengths.astype('f8')
+    if results.class_map.size == 0:
+        zeros = numpy.zeros(results.effective_lengths.size).astype('f8')
+        return (zeros, 0) if return_iters else zeros
+    if x0 is None:
+        x = numpy.ones(transcript_length.size, dtype='f8') / transcript_length
+    else:
+        x = x0.copy()
+    x /= x.sum()
+    quant, owned = _quant_for(results)
+    try:
+        if bootstrap:
+            if seed is None:
+                seed = int.from_bytes(__import__('os').urandom(8), 'little')
+            out, _, iters = quant.bootstrap(1, seed, x, transcript_length)
+            x, iters = out[0], int(iters[0])
+        else:
+            x, iters = quant.em(x, transcript_length, fixed_iters=fixed_iters)
+    finally:
+        if owned:
+            quant.close()
+    x = _tpm(x)
+    return (x, iters) if return_iters else x
+
+
+def bootstrap_quantify(results, x0, n_boot, seed=None):
+    """The `-b N` loop of run() (seekmer/infer.py:79-82) as one device call."""
+    if n_boot <= 0:
+        return []
+    transcript_length = results.effective_lengths.astype('f8')
+    if results.class_map.size == 0:
+        return [numpy.zeros(transcript_length.size, dtype='f8') for _ in range(n_boot)]
+    if seed is None:
+        seed = int.from_bytes(__import__('os').urandom(8), 'little')
+    x = x0.copy()
+    x /= x.sum()
+    quant, owned = _quant_for(results)
+    try:
+        out, _, _ = quant.bootstrap(n_boot, seed, x, transcript_length)
+    finally:
+        if owned:
+            quant.close()
+    return [_tpm(out[b].copy()) for b in range(n_boot)]
+
+
+def em(x, l, class_map, class_count, fixed_iters=0, return_iters=False, device=0):
+    """Expectation-maximization (seekmer/infer.py:133-168)."""
+    class_count = numpy.asarray(class_count, dtype='f8')
+    offsets, targets = _csr_from_class_map(class_map, class_count.size)
+    quant = _QuantHandle.from_csr(numpy.asarray(l).size, offsets, targets, class_count, device)
+    try:
+        x, iters = quant.em(x, l, fixed_iters=fixed_iters)
+    finally:
+        quant.close()
+    return (x, iters) if return_iters else x
+
+
+# ------------------------------------------------------------------- outputs
+def output_results(output_path, index, start_time, results, main_abundance,
+                   bootstrapped_abundance):
+    """Output the quantification results (seekmer/infer.py:171-197)."""
+    run_info = _generate_run_info(bootstrapped_abundance, index, results, start_time)
+    with (output_path / 'run_info.json').open('w') as f:
+        json.dump(run_info, f)
+    est_counts = _infer_est_counts(index, results, main_abundance)
+    _output_abundance_table(output_path, index, results, est_counts, main_abundance)
+    _output_arrays(output_path, index, results, run_info, est_counts, bootstrapped_abundance)
+
+
+def _generate_run_info(bootstrapped_abundance, index, results, start_time):
+    """seekmer/infer.py:200-216"""
+    class_target_count = numpy.bincount(results.class_map[0].astype(numpy.int64),
+                                        minlength=results.class_count.size) \
+        if results.class_map.size else numpy.zeros(results.class_count.size, dtype=numpy.int64)
+    unique_count = results.class_count[class_target_count == 1].sum()
+    return {
+        'n_targets': len(index.transcripts),
+        'n_bootstraps': len(bootstrapped_abundance),
+        'n_processed': results.total,
+        'n_pseudoaligned': results.aligned,
+        'n_unique': int(unique_count),
+        'p_pseudoaligned': results.aligned / results.total,
+        'p_unique': unique_count / results.total,
+        'kallisto_version': '0.44.0',
+        'index_version': 9000,
+        'start_time': start_time.isoformat(sep=' '),
+        'call': ' '.join([shlex.quote(arg) for arg in sys.argv]),
+    }
+
+
+def _output_abundance_table(output_path, index, results, est_counts, main_abundance):
+    """abundance.tsv: target_id, length, eff_length (f4), est_count, tpm; tab
+    separated, floats as %g (seekmer/infer.py:219-230)."""
+    ids = index.transcripts['transcript_id']
+    length = index.transcripts['length']
+    eff = results.effective_lengths.astype('f4')
+    with (output_path / 'abundance.tsv').open('w') as f:
+        f.write('target_id\tlength\teff_length\test_count\ttpm\n')
+        for i in range(len(ids)):
+            f.write('%s\t%g\t%g\t%g\t%g\n' % (ids[i].decode(), float(length[i]), float(eff[i]),
+                                            float(est_counts[i]), float(main_abundance[i])))
+
+
+def _infer_est_counts(index, results, main_abundance):
+    """Estimated read counts from the raw length (seekmer/infer.py:233-252)."""
+    est_counts = main_abundance * index.transcripts['length']
+    est_counts *= results.aligned / est_counts.sum()
+    return est_counts
+
+
+def _output_arrays(output_path, index, results, run_info, est_counts, bootstrapped_abundance):
+    """The datasets of abundance.h5 (seekmer/infer.py:255-325) as abundance.npz:
+    PyTables/h5py are not installed here, so the kallisto-compatible HDF5
+    container itself is out of reach; dataset names
+    are kept ('aux/ids', 'est_counts', 'bootstrap/bs0', ...)."""
+    arrays = {
+        'aux/call': numpy.frombuffer(run_info['call'].encode() or b' ', dtype='S1'),
+        'aux/index_version': numpy.asarray([run_info['index_version']]),
+        'aux/start_time': numpy.frombuffer(run_info['start_time'].encode(), dtype='S1'),
+        'aux/num_bootstrap': numpy.asarray([run_info['n_bootstraps']]),
+        'aux/num_processed': numpy.asarray([run_info['n_processed']]),
+        'aux/kallisto_version': numpy.frombuffer(run_info['kallisto_version'].encode(), dtype='S1'),
+        'aux/ids': numpy.asarray(index.transcripts['transcript_id']),
+        'aux/lengths': numpy.asarray(index.transcripts['length']),
+        'aux/fld': results.fragment_length_frequencies.astype('i4'),
+        'aux/eff_lengths': results.effective_lengths.astype('f8'),
+        'aux/bias_observed': numpy.ones(4096, dtype='i4'),
+        'aux/bias_normalized': numpy.ones(4096, dtype='f8'),
+        'est_counts': est_counts.astype('f8'),
+    }
+    for i, bootstrap in enumerate(bootstrapped_abundance):
+        arrays['bootstrap/bs{}'.format(i)] = bootstrap
+    with (output_path / 'abundance.npz').open('wb') as f:
+        numpy.savez(f, **arrays)
+
+
+def add_subcommand_parser(subparsers):
+    """Add an infer command to the subparsers (seekmer/infer.py:328-353)."""
+    parser = subparsers.add_parser('infer', help='infer transcript abundance')
+    parser.add_argument('index_path', type=pathlib.Path, metavar='index',
+                        help='specify a Seekmer index file')
+    parser.add_argument('output_path', type=pathlib.Path, metavar='output',
+                        help='specify a output folder')
+    parser.add_argument('fastq_paths', type=pathlib.Path, metavar='fastq',
+                        nargs='+', help='specify a FASTQ read file')
+    parser.add_argument('-j', '--jobs', type=int, dest='job_count', metavar='N', default=1,
+                        help='specify the maximum parallel job number')
+    parser.add_argument('-m', '--save-readmap', action='store_true', dest='save_readmap',
+                        help='output an readmap file')
+    parser.add_argument('-s', '--single-ended', action='store_true', dest='single_ended',
+                        help='specify whether the reads are single-ended')
+    parser.add_argument('-b', '--bootstrap', type=int, dest='bootstrap', default=0,
+                        help='specify the number of bootstrapped estimation')
+    parser.add_argument('--device', type=int, default=0, help='GPU ordinal (default 0)')
+    parser.add_argument('--seed', type=int, default=None,
+                        help='seed of the bootstrap resampling (default: random)')

@@ -1,0 +1,171 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle
+on the same inputs.  Integer outputs must be bit-identical."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_product_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _adversarial_reads(seqs, rng, n, read_len):
+    """Reads that exercise the quirks: Ns, lower case, substitutions and indels
+    near junctions, reads from the reverse strand, reads shorter than k,
+    exactly k long, garbage."""
+    comp = bytes.maketrans(b'ACGT', b'TGCA')
+    long_tx = [s for s in seqs if len(s) > read_len + 50]
+    out = []
+    for i in range(n):
+        s = long_tx[rng.integers(len(long_tx))]
+        p = int(rng.integers(0, len(s) - read_len))
+        r = bytearray(s[p:p + read_len].upper())
+        kind = i % 12
+        if kind == 1:
+            r = bytearray(bytes(r).translate(comp)[::-1])
+        elif kind == 2:
+            for _ in range(3):
+                r[int(rng.integers(len(r)))] = ord('N')
+        elif kind == 3:
+            q = int(rng.integers(len(r) - 10))
+            r[q:q + 10] = bytes(r[q:q + 10]).lower()
+        elif kind == 4:
+            for _ in range(int(rng.integers(1, 6))):
+                q = int(rng.integers(len(r)))
+                r[q] = b'ACGT'[int(rng.integers(4))]
+        elif kind == 5:
+            q = int(rng.integers(5, len(r) - 5))
+            del r[q]
+        elif kind == 6:
+            q = int(rng.integers(5, len(r) - 5))
+            r.insert(q, b'ACGT'[int(rng.integers(4))])
+        elif kind == 7:
+            r = r[:int(rng.integers(0, 25))]
+        elif kind == 8:
+            r = r[:25]
+        elif kind == 9:
+            r = bytearray(rng.integers(0, 4, read_len).astype(np.uint8))
+            r = bytearray(bytes(r).translate(bytes.maketrans(bytes(range(4)), b'ACGT')))
+        elif kind == 10:
+            r[:30] = bytes(rng.integers(0, 4, 30).astype(np.uint8)).translate(
+                bytes.maketrans(bytes(range(4)), b'ACGT'))
+        elif kind == 11:
+            r = bytearray(bytes(r).lower())
+        out.append(bytes(r))
+    return out
+
+
+def _run_gpu(index, bases, offsets, n_units, paired):
+    from seekmer_amd import mapper, common
+    result = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, result)
+    rm.map_batch(common.ReadBatch(n_units, bases, offsets, paired))
+    return result, rm.last_batch(n_units)
+
+
+def _compare_units(oracle_result, gpu_units):
+    begin, end, a_entry, a_offset, counts, entries = gpu_units
+    np.testing.assert_array_equal(counts, oracle_result.count)
+    np.testing.assert_array_equal(entries, oracle_result.entries)
+    np.testing.assert_array_equal(begin, oracle_result.begin)
+    np.testing.assert_array_equal(end, oracle_result.end)
+    np.testing.assert_array_equal(a_entry, oracle_result.anchor_entry)
+    np.testing.assert_array_equal(a_offset, oracle_result.anchor_offset)
+
+
+def _compare_tables(oracle, oracle_result, fld, map_result):
+    classes = oracle.Classes()
+    classes.update(oracle_result)
+    offs, ids, counts = classes.export()
+    g_offs, g_ids, g_counts, _, g_fld = map_result.export()
+    np.testing.assert_array_equal(g_fld, fld)
+    np.testing.assert_array_equal(g_offs, offs)
+    np.testing.assert_array_equal(g_ids, ids)
+    np.testing.assert_array_equal(g_counts, counts)
+    assert map_result.sizes()[2] == classes.unaligned
+
+
+def test_reference_21_pairs(oracle, native_libs, chr21, chr21_oracle_index, pairs21):
+    """The reference's own integration datum (seekmer/test/test_mapper.py:71-76)."""
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(pairs21)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, 21, True, fld)
+    result, units = _run_gpu(index, bases, offsets, 21, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+    summarized = result.summarize()
+    assert summarized.unaligned == 0            # the reference's assertion
+    assert summarized.class_count.size == 13    # SURVEY.md section 4, observed on the reference
+
+
+@pytest.mark.parametrize('paired', [True, False])
+def test_chr21_adversarial(oracle, native_libs, chr21, chr21_oracle_index, paired):
+    rng = np.random.default_rng(7)
+    reads = _adversarial_reads(chr21[1], rng, 6000, 100)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = len(reads) // 2 if paired else len(reads)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld)
+    result, units = _run_gpu(index, bases, offsets, n_units, paired)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
+def test_config1_synthetic(oracle, native_libs):
+    """BASELINE.json configs[0]: 1k-transcript synthetic index, 100k 2x75 pairs."""
+    from seekmer_amd import synth, index_builder, infer
+    ids, pool, tx_offsets = synth.transcriptome(1, 100)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    oindex = oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                                lengths=np.diff(tx_offsets))
+    n_units = 100000
+    bases, offsets = synth.reads(1, pool, tx_offsets, 0, n_units, 75, True)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(oindex, bases, offsets, n_units, True, fld)
+    result, units = _run_gpu(index, bases, offsets, n_units, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+    # quantification: effective lengths bit-exact, EM within 1e-9 per fixed step count
+    summarized = result.summarize()
+    eff = oracle.effective_lengths(fld, oindex.lengths)
+    np.testing.assert_array_equal(summarized.effective_lengths, eff)
+    classes = oracle.Classes()
+    classes.update(expected)
+    class_map, class_count = classes.summarize()
+    np.testing.assert_array_equal(summarized.class_map, class_map)
+    np.testing.assert_array_equal(summarized.class_count, class_count)
+    tpm_ref, iters_ref = oracle.quantify(eff, class_map, class_count)
+    tpm_gpu, iters_gpu = infer.quantify(summarized, return_iters=True)
+    assert iters_gpu == iters_ref
+    mask = tpm_ref > 0
+    np.testing.assert_array_equal(tpm_gpu > 0, mask)
+    rel = np.abs(tpm_gpu[mask] - tpm_ref[mask]) / tpm_ref[mask]
+    assert rel.max() < 1e-4, rel.max()          # north_star tolerance on TPM
+    x0 = np.ones(eff.size) / eff
+    x0 /= x0.sum()
+    for k in (1, 2, 5):
+        x_ref, _ = oracle.em(x0, eff, class_map, class_count, fixed_iters=k)
+        x_gpu, it = infer.em(x0, eff, class_map, class_count, fixed_iters=k, return_iters=True)
+        assert it == k
+        np.testing.assert_allclose(x_gpu, x_ref, rtol=1e-9, atol=1e-300)
+
+
+def test_batches_accumulate(oracle, native_libs, chr21, chr21_oracle_index):
+    """Several batches into one MapResult == one big batch (first-seen order kept)."""
+    from seekmer_amd import mapper, common
+    rng = np.random.default_rng(11)
+    reads = _adversarial_reads(chr21[1], rng, 4000, 90)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(reads)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, 2000, True, fld)
+    result = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, result)
+    for lo, hi in ((0, 700), (700, 701), (701, 2000)):
+        sub_off = offsets[2 * lo:2 * hi + 1]
+        rm.map_batch(common.ReadBatch(hi - lo, bases, np.ascontiguousarray(sub_off), True))
+    _compare_tables(oracle, expected, fld, result)
