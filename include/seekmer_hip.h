@@ -48,6 +48,13 @@ const char *skm_last_error(void);
 /* number of visible GPUs; SKM_ERR_NO_DEVICE when there is none */
 int skm_device_count(int *count);
 
+/* Raw HBM buffers for callers that keep batches resident (bench, pipelines). */
+int skm_device_malloc(int device, int64_t bytes, void **out);
+int skm_device_free(int device, void *ptr);
+int skm_device_upload(int device, void *dst, const void *src, int64_t bytes);
+int skm_device_download(int device, void *dst, const void *src, int64_t bytes);
+int skm_device_synchronize(int device);
+
 /* ------------------------------------------------------------------ index
  * Replaces the memoryview binding of KMerIndex.__init__
  * (seekmer/_common.pyx:21-48).  Host arrays are borrowed for the call and
@@ -109,6 +116,9 @@ int skm_mapper_merge(skm_mapper *mapper, int64_t n_classes,
                      const int64_t *class_counts, const int64_t *first_seen,
                      int64_t unaligned, const int64_t *fld);
 int skm_mapper_clear(skm_mapper *mapper);           /* MapResult.clear, mapper.py:143-145 */
+/* Back to the state of a fresh MapResult (counter, unit count AND histogram
+ * zeroed) while keeping every HBM buffer allocated. */
+int skm_mapper_reset(skm_mapper *mapper);
 /* stats[0]=pack kernel ns [1]=map kernel ns [2]=class kernels ns [3]=batches
  * [4]=units (HIP-event times accumulated over batches on the mapper stream) */
 int skm_mapper_timing(skm_mapper *mapper, double stats[8]);

@@ -31,6 +31,11 @@ c_i64 = ctypes.c_int64
 HIP_SYMBOLS = {
     'skm_last_error': (ctypes.c_char_p, []),
     'skm_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'skm_device_malloc': (ctypes.c_int, [ctypes.c_int, c_i64, c_void_pp]),
+    'skm_device_free': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    'skm_device_upload': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_i64]),
+    'skm_device_download': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_i64]),
+    'skm_device_synchronize': (ctypes.c_int, [ctypes.c_int]),
     'skm_index_create': (ctypes.c_int, [ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_int, c_void_pp]),
@@ -50,6 +55,7 @@ HIP_SYMBOLS = {
     'skm_mapper_merge': (ctypes.c_int, [ctypes.c_void_p, c_i64, c_i64p, c_i32p, c_i64p, c_i64p,
                                         c_i64, c_i64p]),
     'skm_mapper_clear': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_mapper_reset': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_timing': (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     'skm_mapper_set_stats': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'skm_mapper_access_stats': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),

@@ -159,6 +159,44 @@ extern "C" int skm_device_count(int *count)
     return SKM_OK;
 }
 
+extern "C" int skm_device_malloc(int device, int64_t bytes, void **out)
+{
+    if (!out || bytes < 0) return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(set_device(device));
+    HIP_TRY(hipMalloc(out, (size_t)std::max<int64_t>(bytes, 1)));
+    return SKM_OK;
+}
+
+extern "C" int skm_device_free(int device, void *ptr)
+{
+    SKM_TRY(set_device(device));
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return SKM_OK;
+}
+
+extern "C" int skm_device_upload(int device, void *dst, const void *src, int64_t bytes)
+{
+    if (!dst || !src || bytes < 0) return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(set_device(device));
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return SKM_OK;
+}
+
+extern "C" int skm_device_download(int device, void *dst, const void *src, int64_t bytes)
+{
+    if (!dst || !src || bytes < 0) return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(set_device(device));
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return SKM_OK;
+}
+
+extern "C" int skm_device_synchronize(int device)
+{
+    SKM_TRY(set_device(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return SKM_OK;
+}
+
 // -------------------------------------------------------------------- index
 extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *contigs,
                                 int64_t n_contigs, const char *sequences, int64_t n_bases,
@@ -671,6 +709,18 @@ extern "C" int skm_mapper_clear(skm_mapper *m)
     return SKM_OK;
 }
 
+extern "C" int skm_mapper_reset(skm_mapper *m)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    SKM_TRY(table_reset(m, m->t.slot_mask + 1));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->last_units = 0;
+    m->last_ids = 0;
+    return SKM_OK;
+}
+
 extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
 {
     if (!m || !stats) return fail(SKM_ERR_ARG, "NULL argument");
@@ -697,6 +747,7 @@ extern "C" int skm_mapper_set_stats(skm_mapper *m, int enable)
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
     std::lock_guard<std::mutex> lock(m->mu);
     m->want_stats = enable != 0;
+    for (auto &v : m->stats_total) v = 0;
     return SKM_OK;
 }
 

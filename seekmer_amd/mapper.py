@@ -216,6 +216,25 @@ class MapResult:
         """Clear the counter (seekmer/mapper.py:143-145)."""
         _native.check(_native.hip().skm_mapper_clear(self._handle))
 
+    def reset(self):
+        """Fresh-MapResult state (counter, totals and histogram) on the same buffers."""
+        _native.check(_native.hip().skm_mapper_reset(self._handle))
+
+    def map_resident(self, d_bases, d_offsets, n_units, paired, max_read_len):
+        """Map a batch that already lives in HBM (device pointers)."""
+        _native.check(_native.hip().skm_mapper_map_batch_device(
+            self._handle, d_bases, d_offsets, n_units, int(bool(paired)), max_read_len))
+
+    def set_stats(self, enable):
+        _native.check(_native.hip().skm_mapper_set_stats(self._handle, int(bool(enable))))
+
+    def access_stats(self):
+        out = (ctypes.c_int64 * 16)()
+        _native.check(_native.hip().skm_mapper_access_stats(self._handle, out))
+        names = ('reads', 'read_bases', 'lookups', 'slots', 'contig_reads', 'targets_copied',
+                 'targets_merged', 'seq_fetches', 'merges', 'tuple_ids')
+        return {n: int(out[i]) for i, n in enumerate(names)}
+
     def timing(self):
         out = (ctypes.c_double * 8)()
         _native.check(_native.hip().skm_mapper_timing(self._handle, out))
