@@ -9,10 +9,15 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* numpy's pairwise summation for contiguous float64 (loops_utils.h.src):
- * n < 8 sequential; n <= 128 eight accumulators; else split at n/2 rounded
- * down to a multiple of 8. */
-double skmo_pairwise_sum(const double *a, int64_t n)
+/* numpy.sum of a contiguous float64 array as numpy 2.2 (the version in this
+ * image) computes it: the reduction is fed to the add loop in blocks of the
+ * ufunc buffer size (8192 elements); inside a block numpy's published pairwise
+ * summation applies (loops_utils.h.src: n < 8 sequential; n <= 128 eight
+ * accumulators; else split at n/2 rounded down to a multiple of 8); the block
+ * sums are accumulated left to right.  Arrays of <= 8192 elements are plain
+ * pairwise sums (also what the numpy 1.15 pinned by environment.yml:30 does
+ * for any length; the two differ by rounding only, ~1e-16 relative). */
+static double pairwise_block(const double *a, int64_t n)
 {
     if (n < 8) {
         double res = 0.0;
@@ -30,8 +35,16 @@ double skmo_pairwise_sum(const double *a, int64_t n)
     } else {
         int64_t n2 = n / 2;
         n2 -= n2 % 8;
-        return skmo_pairwise_sum(a, n2) + skmo_pairwise_sum(a + n2, n - n2);
+        return pairwise_block(a, n2) + pairwise_block(a + n2, n - n2);
     }
+}
+
+double skmo_pairwise_sum(const double *a, int64_t n)
+{
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; i += 8192)
+        acc += pairwise_block(a + i, n - i < 8192 ? n - i : 8192);
+    return acc;
 }
 
 /* seekmer/mapper.py:134-141 -- p = fld / fld.sum(); eff += clip(len - i, 1) * p[i], i ascending */

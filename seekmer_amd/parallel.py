@@ -1,0 +1,95 @@
+"""Multi-GPU host logic (not in the reference, which is single-process).
+
+Reads are independent units, so they shard across ranks with no collective
+while mapping; every rank holds a full index replica.  Exchange steps:
+  * once after mapping: the fragment-length histogram is all-reduced (the
+    effective lengths need the global one) and, when the merged class table is
+    wanted (bit-identical class counts / reference class order), the per-rank
+    tables are all-gathered and merged by global first-seen unit index;
+  * per EM step: one all-reduce(sum) of f64[T] -- done inside the HIP library
+    with RCCL (skm_quant_comm_init); classes stay rank-local because the EM
+    numerators are linear in the class counts.
+`dist` is `torch.distributed` (backend nccl == RCCL on the GPUs, gloo in the
+CPU tests); torch is used for rendezvous and these small host-side exchanges
+only.
+"""
+import numpy
+
+
+def shard_range(n_units, rank, world):
+    """Contiguous shard [first, first + count) of `n_units` for `rank`."""
+    base, extra = divmod(int(n_units), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def allreduce_fld(fld, dist, group=None):
+    """MapResult.merge_fragment_lengths across ranks (seekmer/mapper.py:106-115)."""
+    import torch
+    t = torch.from_numpy(numpy.ascontiguousarray(fld, dtype=numpy.int64).copy())
+    dist.all_reduce(t, group=group)
+    return t.numpy()
+
+
+def gather_tables(table, dist, group=None):
+    """All-gather per-rank class tables.  `table` = dict(offsets, targets,
+    counts, first_seen (GLOBAL unit indices), unaligned)."""
+    world = dist.get_world_size(group)
+    out = [None] * world
+    dist.all_gather_object(out, table, group=group)
+    return out
+
+
+def merge_class_tables(tables):
+    """Counter.update over several tables (seekmer/mapper.py:70): counts add,
+    classes are ordered by the smallest global first-seen unit index, which is
+    the insertion order a single `-j 1` run over all units would produce.
+    Returns dict(offsets, targets, counts, first_seen, unaligned)."""
+    merged = {}
+    unaligned = 0
+    for table in tables:
+        unaligned += int(table['unaligned'])
+        offsets = table['offsets']
+        targets = numpy.asarray(table['targets']).tolist()
+        counts = table['counts']
+        first = table['first_seen']
+        for k in range(len(counts)):
+            key = tuple(targets[offsets[k]:offsets[k + 1]])
+            entry = merged.get(key)
+            if entry is None:
+                merged[key] = [int(counts[k]), int(first[k])]
+            else:
+                entry[0] += int(counts[k])
+                if first[k] < entry[1]:
+                    entry[1] = int(first[k])
+    order = sorted(merged.items(), key=lambda kv: kv[1][1])
+    offsets = numpy.zeros(len(order) + 1, dtype=numpy.int64)
+    numpy.cumsum([len(k) for k, _ in order], out=offsets[1:])
+    return {
+        'offsets': offsets,
+        'targets': numpy.asarray([t for k, _ in order for t in k], dtype=numpy.int32),
+        'counts': numpy.asarray([v[0] for _, v in order], dtype=numpy.int64),
+        'first_seen': numpy.asarray([v[1] for _, v in order], dtype=numpy.int64),
+        'unaligned': unaligned,
+    }
+
+
+def export_table(map_result, first_unit):
+    """The table of a rank's MapResult with first-seen indices made global."""
+    offsets, targets, counts, first_seen, _ = map_result.export()
+    return {'offsets': offsets, 'targets': targets, 'counts': counts,
+            'first_seen': first_seen + int(first_unit), 'unaligned': map_result.sizes()[2]}
+
+
+def broadcast_comm_id(dist, rank, group=None):
+    """RCCL unique id from rank 0 to everyone (128 bytes)."""
+    import ctypes
+    import torch
+    from . import _native
+    buf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        raw = ctypes.create_string_buffer(128)
+        _native.check(_native.hip().skm_comm_unique_id(raw))
+        buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+    dist.broadcast(buf, 0, group=group)
+    return bytes(buf.numpy().tobytes())

@@ -1,0 +1,158 @@
+"""Host-side native code (libseekmer_host.so) and the Python module surface
+that needs no GPU: index builder == oracle bit for bit, FASTQ batching rules,
+synthetic generator determinism."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+ARRAYS = ('kmers', 'contigs', 'sequences', 'targets')
+
+
+def _same_index(product, oracle_index):
+    for name in ARRAYS:
+        assert getattr(product, name).tobytes() == getattr(oracle_index, name).tobytes(), name
+
+
+def test_builder_matches_oracle_chr21(native_libs, oracle, chr21, chr21_oracle_index):
+    from seekmer_amd import index_builder
+    index = index_builder.build(*chr21)
+    _same_index(index, chr21_oracle_index)
+    assert index.transcripts['length'].tolist() == [float(len(s)) for s in chr21[1]]
+    assert index.transcripts['transcript_id'][0] == chr21[0][0]
+
+
+def test_builder_matches_oracle_with_extra(native_libs, oracle):
+    from seekmer_amd import index_builder
+    ids, seqs = index_builder.read_transcripts(os.path.join(GOLDEN, 'human.cdna.21.with_extra.fa.gz'))
+    o_ids, o_seqs = oracle.read_fasta(os.path.join(GOLDEN, 'human.cdna.21.with_extra.fa.gz'))
+    assert (ids, seqs) == (o_ids, o_seqs)
+    index = index_builder.build(ids, seqs)
+    _same_index(index, oracle.build_index(seqs))
+    assert index.transcripts.shape[0] == 3                     # test_index_builder.py:90
+
+
+@pytest.mark.parametrize('seed,genes', [(1, 100), (2, 37)])
+def test_builder_matches_oracle_synthetic(native_libs, oracle, seed, genes):
+    from seekmer_amd import index_builder, synth
+    ids, pool, offsets = synth.transcriptome(seed, genes)
+    index = index_builder.build_pooled(ids, pool, offsets)
+    _same_index(index, oracle.build_index(synth.sequences_of(pool, offsets)))
+
+
+def test_builder_edge_inputs(native_libs, oracle):
+    """Short transcripts are skipped, repeats / palindromes / homopolymers and
+    lower case + N go through the same code paths as in the oracle."""
+    from seekmer_amd import index_builder
+    rng = np.random.default_rng(3)
+    core = bytes(rng.choice(list(b'ACGT'), 400).astype(np.uint8))
+    seqs = [b'ACGT' * 5, core, core[50:300] + core[:80], b'A' * 60, b'AT' * 40,
+            core[:100].lower() + b'NNN' + core[100:200], core[::-1], b'']
+    ids = [b'T%d' % i for i in range(len(seqs))]
+    index = index_builder.build(ids, seqs)
+    _same_index(index, oracle.build_index(seqs))
+
+
+def test_build_rejects_empty(native_libs):
+    from seekmer_amd import index_builder
+    with pytest.raises(ValueError):
+        index_builder.build([], [])                             # index_builder.py:106-107
+
+
+def test_index_save_load_roundtrip(native_libs, tmp_path, chr21):
+    from seekmer_amd import common, index_builder
+    index = index_builder.build(chr21[0][:50], chr21[1][:50])
+    path = tmp_path / 'index.npz'
+    index.save(path)
+    loaded = common.KMerIndex.load(path)
+    for name in ARRAYS:
+        assert getattr(loaded, name).tobytes() == getattr(index, name).tobytes()
+    assert loaded.transcripts['transcript_id'].tolist() == index.transcripts['transcript_id'].tolist()
+
+
+# ---- feeders: the reference's TestReadFeeder (seekmer/test/test_mapper.py:20-68)
+_BASE_SET = set(b'ACTGNactg')
+
+
+def _check_batches(batches, count, reads_per_unit):
+    seen = 0
+    for n, names, reads in batches:
+        seen += 1
+        assert n == count
+        assert len(names) == n
+        assert len(reads) == n * reads_per_unit
+        for read in reads:
+            assert set(read) <= _BASE_SET
+    assert seen == 1
+
+
+@pytest.mark.parametrize('native', [False, True])
+def test_feed_single_ended_reads(native_libs, native):
+    from seekmer_amd import common
+    path = os.path.join(GOLDEN, '20_1.fastq')
+    import pathlib
+    p = pathlib.Path(path)
+    feed = (lambda *ps: common.NativeReadFeeder(ps, paired=False)) if native else common.feed_single_ended_reads
+    _check_batches(feed(p), 21, 1)
+    _check_batches(feed(p, p), 42, 1)                           # buffer carried across files
+
+
+@pytest.mark.parametrize('native', [False, True])
+def test_feed_pair_ended_reads(native_libs, native):
+    import pathlib
+    from seekmer_amd import common
+    paths = [pathlib.Path(GOLDEN) / '20_1.fastq', pathlib.Path(GOLDEN) / '20_2.fastq']
+    feed = (lambda *ps: common.NativeReadFeeder(ps, paired=True)) if native else common.feed_pair_ended_reads
+    _check_batches(feed(*paths), 21, 2)
+    _check_batches(feed(*(paths * 2)), 42, 2)
+    with pytest.raises(ValueError):
+        list(feed(paths[0]))                                     # common.py:178-179
+
+
+def test_native_feeder_equals_python_feeder(native_libs, tmp_path):
+    """Same names, same reads, same batch boundaries -- incl. CRLF, blank
+    padding, a last line without newline, gzip input and small batches."""
+    import gzip
+    import pathlib
+    from seekmer_amd import common
+    rng = np.random.default_rng(9)
+    lines1, lines2 = [], []
+    for i in range(1000):
+        for lines, mate in ((lines1, 1), (lines2, 2)):
+            n = int(rng.integers(25, 120))
+            seq = bytes(rng.choice(list(b'ACGTNacgt'), n).astype(np.uint8))
+            eol = b'\r\n' if i % 7 == 0 else b'\n'
+            lines += [b'@read%d/%d extra' % (i, mate) + eol, b'  ' + seq + b' ' + eol, b'+' + eol,
+                      b'I' * n + eol]
+    lines1[-1] = lines1[-1].rstrip()
+    lines2[-1] = lines2[-1].rstrip()
+    p1, p2 = tmp_path / 'a_1.fastq', tmp_path / 'a_2.fastq.gz'
+    p1.write_bytes(b''.join(lines1))
+    with gzip.open(str(p2), 'wb') as f:
+        f.write(b''.join(lines2))
+    old = common.BUFFER_SIZE
+    try:
+        common.BUFFER_SIZE = 300
+        expected = [(n, list(names), list(reads)) for n, names, reads in
+                    common.feed_pair_ended_reads(pathlib.Path(p1), pathlib.Path(p2))]
+    finally:
+        common.BUFFER_SIZE = old
+    got = [(b.count, b.names, b.reads) for b in
+           common.NativeReadFeeder([p1, p2], paired=True, batch_units=300)]
+    assert got == expected
+    assert [g[0] for g in got] == [300, 300, 300, 100]
+
+
+def test_synth_is_deterministic_and_sliceable(native_libs):
+    from seekmer_amd import synth
+    ids, pool, offsets = synth.transcriptome(5, 30)
+    ids2, pool2, offsets2 = synth.transcriptome(5, 30)
+    assert pool.tobytes() == pool2.tobytes() and offsets.tolist() == offsets2.tolist()
+    assert set(pool[:-1].tobytes()) <= set(b'ACGT')
+    full, _ = synth.reads(5, pool, offsets, 0, 5000, 75, True, n_threads=4)
+    part, _ = synth.reads(5, pool, offsets, 1234, 100, 75, True, n_threads=1)
+    assert part[:-1].tobytes() == full[1234 * 150:(1234 + 100) * 150].tobytes()
+    single, o = synth.reads(5, pool, offsets, 0, 10, 100, False)
+    assert o.tolist() == list(range(0, 1001, 100))
