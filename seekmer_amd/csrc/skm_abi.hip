@@ -128,14 +128,13 @@ struct skm_quant {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     std::mutex mu;
-    int64_t n_tx = 0, n_classes = 0, n_ids = 0;
-    DBuf<int64_t> cls_offset;
-    DBuf<int32_t> cls_len;
-    DBuf<int32_t> ids;
-    DBuf<double> cls_count, cls_count_saved;
-    DBuf<double> eff_len, x0, x1, acc;
+    int64_t n_tx = 0, n_classes = 0, n_ids = 0, n_rows = 0;
+    DBuf<int64_t> cls_offset, row_start, tx_row;
+    DBuf<int32_t> ids, tx_cls, row_tx;
+    DBuf<double> cls_count, cls_count_saved, inner, row_sum;
+    DBuf<double> eff_len, x0, x1, acc, part_max;
+    DBuf<unsigned int> part_flags;
     DBuf<unsigned long long> ctl, cum, draw;
-    bool have_cum = false;
     double n_total = 0;
     // RCCL (loaded lazily)
     void *comm = nullptr;
@@ -782,15 +781,52 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     q->n_ids = n_ids;
     HIP_TRY(hipStreamCreate(&q->stream));
     for (auto &e : q->ev) HIP_TRY(hipEventCreate(&e));
-    SKM_TRY(q->cls_offset.ensure(std::max<int64_t>(n_classes, 1)));
-    SKM_TRY(q->cls_len.ensure(std::max<int64_t>(n_classes, 1)));
-    SKM_TRY(q->cls_count.ensure(std::max<int64_t>(n_classes, 1)));
-    SKM_TRY(q->ids.ensure(std::max<int64_t>(n_ids, 1)));
-    SKM_TRY(q->eff_len.ensure(std::max<int64_t>(n_tx, 1)));
-    SKM_TRY(q->x0.ensure(std::max<int64_t>(n_tx, 1)));
-    SKM_TRY(q->x1.ensure(std::max<int64_t>(n_tx, 1)));
-    SKM_TRY(q->acc.ensure(std::max<int64_t>(n_tx, 1)));
+    const size_t C = (size_t)std::max<int64_t>(n_classes, 1), M = (size_t)std::max<int64_t>(n_ids, 1);
+    const size_t T = (size_t)std::max<int64_t>(n_tx, 1);
+    const size_t R = (size_t)quant_rows_upper_bound(n_tx, n_ids);
+    SKM_TRY(q->cls_offset.ensure(C + 1));
+    SKM_TRY(q->cls_count.ensure(C));
+    SKM_TRY(q->inner.ensure(C));
+    SKM_TRY(q->ids.ensure(M));
+    SKM_TRY(q->tx_cls.ensure(M));
+    SKM_TRY(q->tx_row.ensure(T + 1));
+    SKM_TRY(q->row_start.ensure(R + 1));
+    SKM_TRY(q->row_tx.ensure(R));
+    SKM_TRY(q->row_sum.ensure(R));
+    SKM_TRY(q->eff_len.ensure(T));
+    SKM_TRY(q->x0.ensure(T));
+    SKM_TRY(q->x1.ensure(T));
+    SKM_TRY(q->acc.ensure(T));
     SKM_TRY(q->ctl.ensure(16));
+    SKM_TRY(q->part_max.ensure(EM_FINAL_BLOCKS));
+    SKM_TRY(q->part_flags.ensure(EM_FINAL_BLOCKS));
+    return SKM_OK;
+}
+
+QuantBuild quant_build_view(skm_quant *q)
+{
+    QuantBuild b{};
+    b.n_tx = q->n_tx;
+    b.n_classes = q->n_classes;
+    b.n_ids = q->n_ids;
+    b.cls_offset = q->cls_offset.p;
+    b.ids = q->ids.p;
+    b.cls_count = q->cls_count.p;
+    b.tx_cls = q->tx_cls.p;
+    b.tx_row = q->tx_row.p;
+    b.row_start = q->row_start.p;
+    b.row_tx = q->row_tx.p;
+    b.n_rows_cap = (int64_t)q->row_tx.cap;
+    return b;
+}
+
+int quant_transpose(skm_quant *q)
+{
+    QuantBuild b = quant_build_view(q);
+    const int64_t rows = quant_build_transpose(b, q->stream);
+    if (rows < 0) return fail(SKM_ERR_HIP, "building the transcript-major class view failed (%lld): %s",
+                              (long long)rows, hipGetErrorString(hipGetLastError()));
+    q->n_rows = rows;
     return SKM_OK;
 }
 
@@ -841,10 +877,16 @@ EmProblem em_problem(skm_quant *q, double rel_tol, double x_floor, int64_t max_i
     EmProblem p{};
     p.n_tx = q->n_tx;
     p.n_classes = q->n_classes;
+    p.n_rows = q->n_rows;
     p.cls_offset = q->cls_offset.p;
-    p.cls_len = q->cls_len.p;
     p.ids = q->ids.p;
     p.cls_count = q->cls_count.p;
+    p.inner = q->inner.p;
+    p.row_start = q->row_start.p;
+    p.row_tx = q->row_tx.p;
+    p.tx_cls = q->tx_cls.p;
+    p.tx_row = q->tx_row.p;
+    p.row_sum = q->row_sum.p;
     p.eff_len = q->eff_len.p;
     p.x[0] = q->x0.p;
     p.x[1] = q->x1.p;
@@ -853,6 +895,8 @@ EmProblem em_problem(skm_quant *q, double rel_tol, double x_floor, int64_t max_i
     p.rel_tol = rel_tol;
     p.x_floor = x_floor;
     p.ctl = q->ctl.p;
+    p.part_max = q->part_max.p;
+    p.part_flags = q->part_flags.p;
     p.max_iters = max_iters;
     p.fixed_iters = fixed_iters;
     return p;
@@ -872,7 +916,6 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     }
     EmProblem p = em_problem(q, rel_tol, x_floor, max_iters, fixed_iters);
     p.n_total = n_total;
-    HIP_TRY(hipMemsetAsync(q->acc.p, 0, (size_t)std::max<int64_t>(q->n_tx, 1) * 8, q->stream));
     HIP_TRY(hipMemsetAsync(q->ctl.p, 0, 16 * 8, q->stream));
     unsigned long long ctl[8] = {0};
     int64_t k = 0;
@@ -880,12 +923,15 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     HIP_TRY(hipEventRecord(q->ev[0], q->stream));
     for (;;) {
         for (int64_t i = 0; i < chunk; ++i, ++k) {
-            launch_em_scatter(p, (int)(k & 1), q->stream);
-            if (q->comm)
+            launch_em_inner(p, (int)(k & 1), q->stream);
+            launch_em_rows(p, (int)(k & 1), q->stream);
+            if (q->comm) {
+                launch_em_rows_to_acc(p, q->stream);
                 NCCL_TRY(g_rccl.AllReduce(q->acc.p, q->acc.p, (size_t)q->n_tx, NCCL_FLOAT64, NCCL_SUM,
                                           q->comm, q->stream));
-            launch_em_finalize(p, (int)(k & 1), q->stream);
-            q->launches += 2;
+            }
+            launch_em_finalize(p, (int)(k & 1), q->comm != nullptr, q->stream);
+            q->launches += q->comm ? 4 : 3;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(ctl, q->ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, q->stream));
@@ -899,7 +945,7 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     q->t_em_ns += ms * 1e6;
     q->iters_total += (double)ctl[1];
     if (iters_out) *iters_out = (int64_t)ctl[1];
-    if (ctl[6]) return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
+    if (ctl[3]) return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
     return SKM_OK;
 }
 
@@ -915,29 +961,30 @@ extern "C" int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
     int n_dev = 0;
     SKM_TRY(skm_device_count(&n_dev));
     if (device < 0 || device >= n_dev) return fail(SKM_ERR_ARG, "device %d out of range", device);
-    const int64_t M = n_classes ? class_offsets[n_classes] : 0;
-    std::vector<int32_t> len(std::max<int64_t>(n_classes, 1));
+    const int64_t M = n_classes ? class_offsets[n_classes] - class_offsets[0] : 0;
     double total = 0;
     for (int64_t c = 0; c < n_classes; ++c) {
-        const int64_t l = class_offsets[c + 1] - class_offsets[c];
-        if (l < 0 || l > INT32_MAX) return fail(SKM_ERR_ARG, "class offsets are not monotone");
-        len[c] = (int32_t)l;
+        if (class_offsets[c + 1] < class_offsets[c]) return fail(SKM_ERR_ARG, "class offsets are not monotone");
         total += class_counts[c];
     }
-    for (int64_t j = 0; j < M; ++j)
-        if (class_targets[j] < 0 || class_targets[j] >= n_tx)
-            return fail(SKM_ERR_ARG, "class target %d outside [0, n_tx)", class_targets[j]);
+    for (int64_t j = 0; j < M; ++j) {
+        const int32_t t = class_targets[class_offsets[0] + j];
+        if (t < 0 || t >= n_tx) return fail(SKM_ERR_ARG, "class target %d outside [0, n_tx)", t);
+    }
     SKM_TRY(set_device(device));
     skm_quant *q = new skm_quant();
     int rc = quant_alloc(q, device, n_tx, n_classes, M);
     if (rc != SKM_OK) { delete q; return rc; }
+    std::vector<int64_t> rebased(n_classes + 1, 0);
+    for (int64_t c = 0; c <= n_classes && n_classes; ++c) rebased[c] = class_offsets[c] - class_offsets[0];
+    HIP_TRY(hipMemcpy(q->cls_offset.p, rebased.data(), (n_classes + 1) * 8, hipMemcpyHostToDevice));
     if (n_classes) {
-        HIP_TRY(hipMemcpy(q->cls_offset.p, class_offsets, n_classes * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(q->cls_len.p, len.data(), n_classes * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(q->cls_count.p, class_counts, n_classes * 8, hipMemcpyHostToDevice));
-        if (M) HIP_TRY(hipMemcpy(q->ids.p, class_targets, M * 4, hipMemcpyHostToDevice));
+        if (M) HIP_TRY(hipMemcpy(q->ids.p, class_targets + class_offsets[0], M * 4, hipMemcpyHostToDevice));
     }
     q->n_total = total;
+    rc = quant_transpose(q);
+    if (rc != SKM_OK) { skm_quant_destroy(q); return rc; }
     *out = q;
     return SKM_OK;
 }
@@ -954,16 +1001,14 @@ extern "C" int skm_quant_create_from_mapper(skm_mapper *m, int64_t n_tx, skm_qua
     unsigned long long ctr[4];
     HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));
     q->n_total = (double)(ctr[CTR_UNITS] - ctr[CTR_UNALIGNED]);
-    if (C) {
-        DBuf<unsigned long long> cur;
-        SKM_TRY(cur.ensure(1));
-        HIP_TRY(hipMemsetAsync(cur.p, 0, 8, m->stream));
-        launch_class_compact(m->t, q->cls_offset.p, q->cls_len.p, q->cls_count.p, nullptr, cur.p, m->stream);
-        HIP_TRY(hipGetLastError());
-        if (M) HIP_TRY(hipMemcpyAsync(q->ids.p, m->arena.p, (size_t)M * 4, hipMemcpyDeviceToDevice, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        cur.release();
+    QuantBuild b = quant_build_view(q);
+    rc = quant_build_from_table(m->t, C, M, b, q->stream);
+    if (rc != 0) {
+        skm_quant_destroy(q);
+        return fail(SKM_ERR_HIP, "ordering the class table failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
     }
+    rc = quant_transpose(q);
+    if (rc != SKM_OK) { skm_quant_destroy(q); return rc; }
     *out = q;
     return SKM_OK;
 }
@@ -974,9 +1019,11 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     (void)hipSetDevice(q->device);
     if (q->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(q->comm);
     (void)hipStreamSynchronize(q->stream);
-    q->cls_offset.release(); q->cls_len.release(); q->ids.release(); q->cls_count.release();
-    q->cls_count_saved.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
-    q->acc.release(); q->ctl.release(); q->cum.release(); q->draw.release();
+    q->cls_offset.release(); q->row_start.release(); q->tx_row.release(); q->ids.release();
+    q->tx_cls.release(); q->row_tx.release(); q->cls_count.release(); q->cls_count_saved.release();
+    q->inner.release(); q->row_sum.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
+    q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
+    q->cum.release(); q->draw.release();
     for (auto &e : q->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(q->stream);
     delete q;
@@ -1008,7 +1055,6 @@ extern "C" int skm_quant_set_counts(skm_quant *q, const double *class_counts)
     if (q->n_classes)
         HIP_TRY(hipMemcpy(q->cls_count.p, class_counts, q->n_classes * 8, hipMemcpyHostToDevice));
     q->n_total = total;
-    q->have_cum = false;
     return SKM_OK;
 }
 

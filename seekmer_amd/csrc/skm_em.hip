@@ -3,108 +3,161 @@
 // /root/reference/seekmer/infer.py:133-168 (em), mapper.py:134-141
 // (effective_lengths) and the scipy draw of infer.py:108-111.
 //
-// One EM step is two launches on one stream:
-//   em_scatter  -- one lane per class: S_c = sum of x over the tuple (in tuple
-//                  order, as numpy.bincount accumulates it), inner_c = S_c /
-//                  count_c, then x_t / inner_c is scatter-added into acc[t]
-//                  with f64 memory-side atomics
-//   em_finalize -- one lane per transcript: x'_t = acc_t / l_t / n, NaN -> 0,
-//                  relative change against x_t, block max -> atomicMax; the
-//                  last block to finish evaluates the reference's stopping rule
-//                  and latches `done`, after which every later launch of the
-//                  chunk is a no-op (so the host can enqueue steps in chunks
-//                  and still stop at exactly the reference's iteration count).
-// The step is HBM/L2-bound integer-indexed gather + scatter: no MFMA.
+// One EM step is a two-sided gather over two CSR views of the same
+// (class, transcript) pairs, three launches on one stream and no
+// floating-point atomics, so every step is bitwise reproducible:
+//   em_inner     -- one lane per class: S_c = sum of x over the tuple in tuple
+//                   order (as numpy.bincount accumulates it), inner_c = S_c /
+//                   count_c                                   (infer.py:155-156)
+//   em_rows      -- 8 lanes per row (a run of <= 512 classes of ONE transcript):
+//                   sum of x_t / inner_c over the run          (infer.py:157)
+//   em_finalize  -- one lane per transcript: x'_t = (sum of its rows) / l_t /
+//                   n, NaN -> 0, relative change against x_t; block partials;
+//                   the last block to finish evaluates the reference's stopping
+//                   rule (infer.py:160) and latches `done`, after which every
+//                   later launch is a no-op -- the host enqueues steps in
+//                   chunks and still stops at exactly the reference's count.
+// All three are gather/stream kernels bound by HBM/L2 bandwidth: no MFMA.
 #include "skm_kernels.h"
 
 namespace skm {
 
-enum { CTL_DONE = 0, CTL_ITERS = 1, CTL_TICKET = 2, CTL_MAX = 3, CTL_ANY = 4, CTL_NAN = 5,
-       CTL_UNDEFINED = 6 };
+enum { CTL_DONE = 0, CTL_ITERS = 1, CTL_TICKET = 2, CTL_UNDEFINED = 3 };
 
 __global__ void __launch_bounds__(256)
-em_scatter_kernel(EmProblem p, int parity)
+em_inner_kernel(EmProblem p, int parity)
 {
     if (p.ctl[CTL_DONE]) return;
     const double *__restrict__ x = p.x[parity];
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < p.n_classes;
          c += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t off = p.cls_offset[c];
-        const int len = p.cls_len[c];
+        const int64_t begin = p.cls_offset[c], end = p.cls_offset[c + 1];
         double s = 0.0;
-        for (int j = 0; j < len; ++j) s += x[p.ids[off + j]];
-        const double inner = s / p.cls_count[c];                 // infer.py:155-156
-        for (int j = 0; j < len; ++j) {
-            const int32_t t = p.ids[off + j];
-            atomicAdd(&p.acc[t], x[t] / inner);                  // infer.py:157
-        }
+        for (int64_t j = begin; j < end; ++j) s += x[p.ids[j]];
+        p.inner[c] = s / p.cls_count[c];
     }
 }
 
 __global__ void __launch_bounds__(256)
+em_rows_kernel(EmProblem p, int parity)
+{
+    if (p.ctl[CTL_DONE]) return;
+    const double *__restrict__ x = p.x[parity];
+    const int sub = threadIdx.x & 7;
+    for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; r < p.n_rows;
+         r += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int64_t begin = p.row_start[r], end = p.row_start[r + 1];
+        const double xt = x[p.row_tx[r]];
+        double s = 0.0;
+        for (int64_t e = begin + sub; e < end; e += 8) s += xt / p.inner[p.tx_cls[e]];
+        s += __shfl_xor(s, 4, 8);
+        s += __shfl_xor(s, 2, 8);
+        s += __shfl_xor(s, 1, 8);
+        if (sub == 0) p.row_sum[r] = s;
+    }
+}
+
+// multi-GPU only: rows -> per-transcript numerators for the all-reduce
+__global__ void __launch_bounds__(256)
+em_rows_to_acc_kernel(EmProblem p)
+{
+    if (p.ctl[CTL_DONE]) return;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < p.n_tx;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        double a = 0.0;
+        for (int64_t r = p.tx_row[t]; r < p.tx_row[t + 1]; ++r) a += p.row_sum[r];
+        p.acc[t] = a;
+    }
+}
+
+template <bool FROM_ACC>
+__global__ void __launch_bounds__(256)
 em_finalize_kernel(EmProblem p, int parity)
 {
     if (p.ctl[CTL_DONE]) return;
+    __shared__ double s_max[4];
+    __shared__ unsigned int s_flags[4];
+    __shared__ bool s_last;
     const double *__restrict__ x_old = p.x[parity];
     double *__restrict__ x_new = p.x[parity ^ 1];
     double local_max = 0.0;
-    int any = 0, nan = 0;
+    unsigned int flags = 0;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < p.n_tx;
          t += (int64_t)gridDim.x * blockDim.x) {
-        double v = p.acc[t] / p.eff_len[t] / p.n_total;          // infer.py:158
+        double a;
+        if (FROM_ACC) {
+            a = p.acc[t];
+        } else {
+            a = 0.0;
+            for (int64_t r = p.tx_row[t]; r < p.tx_row[t + 1]; ++r) a += p.row_sum[r];
+        }
+        double v = a / p.eff_len[t] / p.n_total;                 // infer.py:158
         if (v != v) v = 0.0;                                     // infer.py:159
-        p.acc[t] = 0.0;
         x_new[t] = v;
         if (v > p.x_floor) {                                     // infer.py:160
             const double r = fabs(v - x_old[t]) / v;
-            if (r != r) nan = 1;
+            if (r != r) flags |= 2u;
             else if (r > local_max) local_max = r;
-            any = 1;
+            flags |= 1u;
         }
     }
-    // wave reduce, then one set of atomics per wave
     for (int d = 32; d > 0; d >>= 1) {
         const double o = __shfl_xor(local_max, d, 64);
         local_max = o > local_max ? o : local_max;
-        any |= __shfl_xor(any, d, 64);
-        nan |= __shfl_xor(nan, d, 64);
+        flags |= __shfl_xor(flags, d, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (any) {
-            atomicMax(&p.ctl[CTL_MAX], (unsigned long long)__double_as_longlong(local_max));
-            atomicOr(&p.ctl[CTL_ANY], 1ULL);
-        }
-        if (nan) atomicOr(&p.ctl[CTL_NAN], 1ULL);
-    }
-    __threadfence();
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_max[wave] = local_max; s_flags[wave] = flags; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        double m = s_max[0];
+        unsigned int f = s_flags[0];
+        for (int w = 1; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
+        __hip_atomic_store(&p.part_max[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.part_flags[blockIdx.x], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                         // release the partials ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // ... before the ticket
         const unsigned long long ticket = atomicAdd(&p.ctl[CTL_TICKET], 1ULL);
-        if (ticket == gridDim.x - 1) {
-            // last block: all other blocks' atomics are complete (memory-side RMWs)
-            const unsigned long long max_bits = atomicAdd(&p.ctl[CTL_MAX], 0ULL);
-            const unsigned long long any_f = atomicAdd(&p.ctl[CTL_ANY], 0ULL);
-            const unsigned long long nan_f = atomicAdd(&p.ctl[CTL_NAN], 0ULL);
-            const unsigned long long iters = p.ctl[CTL_ITERS] + 1;
-            bool done;
-            if (p.fixed_iters > 0) {
-                done = (int64_t)iters >= p.fixed_iters;
-            } else if (!any_f) {
-                p.ctl[CTL_UNDEFINED] = 1;     // numpy raises on max() of an empty selection
-                done = true;
-            } else {
-                const double m = __longlong_as_double((long long)max_bits);
-                done = nan_f || !(m > p.rel_tol);
-                if (p.max_iters > 0 && (int64_t)iters >= p.max_iters) done = true;
-            }
-            p.ctl[CTL_ITERS] = iters;
-            p.ctl[CTL_TICKET] = 0;
-            p.ctl[CTL_MAX] = 0;
-            p.ctl[CTL_ANY] = 0;
-            p.ctl[CTL_NAN] = 0;
-            __threadfence();
-            p.ctl[CTL_DONE] = done ? 1ULL : 0ULL;
+        s_last = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // last block: every other block's partials are published
+    __threadfence();
+    double m = 0.0;
+    unsigned int f = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+        const double o = __hip_atomic_load(&p.part_max[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = o > m ? o : m;
+        f |= __hip_atomic_load(&p.part_flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const double o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+        f |= __shfl_xor(f, d, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_max[wave] = m; s_flags[wave] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
+        m = s_max[0] > m ? s_max[0] : m;
+        f |= s_flags[0];
+        const unsigned long long iters = p.ctl[CTL_ITERS] + 1;
+        bool done;
+        if (p.fixed_iters > 0) {
+            done = (int64_t)iters >= p.fixed_iters;
+        } else if (!(f & 1u)) {
+            p.ctl[CTL_UNDEFINED] = 1;         // numpy raises on max() of an empty selection
+            done = true;
+        } else {
+            done = (f & 2u) || !(m > p.rel_tol);                 // NaN propagates through max()
+            if (p.max_iters > 0 && (int64_t)iters >= p.max_iters) done = true;
         }
+        p.ctl[CTL_ITERS] = iters;
+        p.ctl[CTL_TICKET] = 0;
+        __threadfence();
+        p.ctl[CTL_DONE] = done ? 1ULL : 0ULL;
     }
 }
 
@@ -209,14 +262,38 @@ static inline unsigned grid_for(int64_t n, int64_t cap = 256 * 16)
     return (unsigned)blocks;
 }
 
-void launch_em_scatter(const EmProblem &p, int parity, hipStream_t stream)
+static inline unsigned chip_grid(int64_t work_items, int items_per_block)
 {
-    hipLaunchKernelGGL(em_scatter_kernel, dim3(grid_for(p.n_classes)), dim3(256), 0, stream, p, parity);
+    int64_t blocks = (work_items + items_per_block - 1) / items_per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    return (unsigned)blocks;
 }
 
-void launch_em_finalize(const EmProblem &p, int parity, hipStream_t stream)
+void launch_em_inner(const EmProblem &p, int parity, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_finalize_kernel, dim3(grid_for(p.n_tx, 1024)), dim3(256), 0, stream, p, parity);
+    hipLaunchKernelGGL(em_inner_kernel, dim3(chip_grid(p.n_classes, 256)), dim3(256), 0, stream, p, parity);
+}
+
+void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_rows_kernel, dim3(chip_grid(p.n_rows, 32)), dim3(256), 0, stream, p, parity);
+}
+
+void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_rows_to_acc_kernel, dim3(chip_grid(p.n_tx, 256)), dim3(256), 0, stream, p);
+}
+
+void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream)
+{
+    int64_t blocks = (p.n_tx + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
+    if (from_acc)
+        hipLaunchKernelGGL(em_finalize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, parity);
+    else
+        hipLaunchKernelGGL(em_finalize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, parity);
 }
 
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,

@@ -67,24 +67,58 @@ void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *c
                         const int32_t *class_targets, const int64_t *class_counts,
                         const int64_t *first_seen, hipStream_t stream);
 
-// ---- quantification (skm_em.hip)
+// ---- quantification (skm_em.hip, skm_quant_setup.hip)
+constexpr int EM_ROW_CAP = 512;   // longest run of one transcript's classes summed by one lane group
+
 struct EmProblem {
-    int64_t n_tx, n_classes;
-    const int64_t *cls_offset;    // [C] start of each class in `ids`
-    const int32_t *cls_len;       // [C]
-    const int32_t *ids;           // transcript ids
+    int64_t n_tx, n_classes, n_rows;
+    // class-major side: class c owns ids[cls_offset[c] .. cls_offset[c+1])
+    const int64_t *cls_offset;    // [C+1]
+    const int32_t *ids;           // [M] transcript ids, tuple order inside a class
     const double *cls_count;      // [C]
+    double *inner;                // [C] S_c / count_c of the current step
+    // transcript-major side: rows = runs of <= EM_ROW_CAP entries of one transcript
+    const int64_t *row_start;     // [R+1] into tx_cls
+    const int32_t *row_tx;        // [R]
+    const int32_t *tx_cls;        // [M] class index of every (transcript, class) pair, by transcript
+    const int64_t *tx_row;        // [T+1] rows of each transcript
+    double *row_sum;              // [R]
     const double *eff_len;        // [T]
     double *x[2];                 // ping-pong abundance vectors
-    double *acc;                  // [T] scatter-add target (numerators)
-    double n_total;               // sum of class counts
+    double *acc;                  // [T] numerators (multi-GPU all-reduce buffer)
+    double n_total;               // sum of class counts over all ranks
     double rel_tol, x_floor;
-    // control block: [0]=done [1]=iters [2]=ticket [3]=max bits [4]=any [5]=nan [6]=undefined
+    // control block: [0]=done [1]=iters [2]=ticket [3]=undefined; partials follow
     unsigned long long *ctl;
+    double *part_max;             // [EM_FINAL_BLOCKS]
+    unsigned int *part_flags;     // [EM_FINAL_BLOCKS] bit0 = any, bit1 = nan
     int64_t max_iters, fixed_iters;
 };
-void launch_em_scatter(const EmProblem &p, int parity, hipStream_t stream);
-void launch_em_finalize(const EmProblem &p, int parity, hipStream_t stream);
+constexpr int EM_FINAL_BLOCKS = 256;
+void launch_em_inner(const EmProblem &p, int parity, hipStream_t stream);
+void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream);
+void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream);
+void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream);
+
+// device-side construction of the two CSR views (hipCUB sorts/scans + small kernels)
+struct QuantBuild {
+    int64_t n_tx, n_classes, n_ids;
+    int64_t *cls_offset;          // [C+1] out
+    int32_t *ids;                 // [M]   out (class-major)
+    double *cls_count;            // [C]   out
+    int32_t *tx_cls;              // [M]   out
+    int64_t *tx_row;              // [T+1] out
+    int64_t *row_start;           // [R+1] out (capacity n_rows_cap + 1)
+    int32_t *row_tx;              // [R]   out
+    int64_t n_rows_cap;
+};
+// classes taken from a mapper's table, ordered by first-seen unit (the reference's class order)
+int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids, QuantBuild &q,
+                           hipStream_t stream);
+// builds tx_cls / tx_row / row_* from cls_offset + ids; returns the number of rows (or < 0)
+int64_t quant_build_transpose(QuantBuild &q, hipStream_t stream);
+int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids);
+
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
                               double *out, hipStream_t stream);
 void launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_t n_draws,

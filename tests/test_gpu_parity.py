@@ -169,3 +169,99 @@ def test_batches_accumulate(oracle, native_libs, chr21, chr21_oracle_index):
         sub_off = offsets[2 * lo:2 * hi + 1]
         rm.map_batch(common.ReadBatch(hi - lo, bases, np.ascontiguousarray(sub_off), True))
     _compare_tables(oracle, expected, fld, result)
+
+
+def test_em_device_table_path_and_determinism(oracle, native_libs):
+    """skm_quant_create_from_mapper (table never leaves HBM, classes ordered by
+    first-seen on the device) == host CSR path == oracle; two runs are bitwise equal."""
+    from seekmer_amd import synth, index_builder, infer
+    ids, pool, tx_offsets = synth.transcriptome(6, 60)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    n_units = 30000
+    bases, offsets = synth.reads(6, pool, tx_offsets, 0, n_units, 100, True)
+    result, _ = _run_gpu(index, bases, offsets, n_units, True)
+    summarized = result.summarize()
+    eff = summarized.effective_lengths
+    x0 = np.ones(eff.size) / eff
+    x0 /= x0.sum()
+    quant = infer._QuantHandle.from_map_result(result, eff.size)
+    x_dev, it_dev = quant.em(x0, eff)
+    x_dev2, it_dev2 = quant.em(x0, eff)
+    quant.close()
+    assert it_dev == it_dev2
+    np.testing.assert_array_equal(x_dev, x_dev2)
+    x_host, it_host = infer.em(x0, eff, summarized.class_map, summarized.class_count, return_iters=True)
+    assert it_host == it_dev
+    np.testing.assert_array_equal(x_host, x_dev)       # same class order -> same arithmetic
+    x_ref, it_ref = oracle.em(x0, eff, summarized.class_map, summarized.class_count)
+    assert it_ref == it_dev
+    np.testing.assert_allclose(x_dev, x_ref, rtol=1e-9, atol=1e-300)
+
+
+def test_em_skewed_and_degenerate_tables(oracle, native_libs):
+    """A transcript in thousands of classes (several 512-entry rows), duplicate
+    ids inside a tuple, transcripts in no class, zero counts (bootstrap), and
+    the NaN -> 0 rule."""
+    from seekmer_amd import infer
+    rng = np.random.default_rng(5)
+    n_tx, n_classes = 300, 4000
+    sizes = rng.integers(1, 6, n_classes)
+    cls = np.repeat(np.arange(n_classes), sizes)
+    tx = rng.integers(1, n_tx - 20, cls.size)           # ids >= n_tx - 20 never appear
+    tx[rng.random(cls.size) < 0.35] = 7                  # heavy transcript
+    class_map = np.vstack([cls, tx]).astype(np.int64)
+    class_count = rng.integers(0, 40, n_classes).astype('f8')
+    class_count[:5] = 0
+    l = rng.uniform(50, 3000, n_tx)
+    x0 = 1.0 / l
+    x0 /= x0.sum()
+    for k in (1, 3):
+        x_ref, _ = oracle.em(x0, l, class_map, class_count, fixed_iters=k)
+        x_gpu, it = infer.em(x0, l, class_map, class_count, fixed_iters=k, return_iters=True)
+        assert it == k
+        np.testing.assert_allclose(x_gpu, x_ref, rtol=1e-9, atol=1e-300)
+    x_ref, it_ref = oracle.em(x0, l, class_map, class_count)
+    x_gpu, it_gpu = infer.em(x0, l, class_map, class_count, return_iters=True)
+    assert it_gpu == it_ref
+    np.testing.assert_allclose(x_gpu, x_ref, rtol=1e-8, atol=1e-300)
+    # class_map rows in arbitrary order are accepted (pairs keep their order inside a class)
+    perm = rng.permutation(cls.size)
+    x_perm, _ = infer.em(x0, l, class_map[:, perm], class_count, fixed_iters=2, return_iters=True)
+    x_ref2, _ = oracle.em(x0, l, class_map[:, np.sort(perm, kind='stable')], class_count, fixed_iters=2)
+    np.testing.assert_allclose(x_perm, x_ref2, rtol=1e-9, atol=1e-300)
+
+
+def test_bootstrap_draw_and_em(oracle, native_libs):
+    """The multinomial draw is only distributional (the reference draws from
+    numpy's unseeded generator): totals exact, mean n*p within 6 sigma; the EM
+    from the drawn counts equals the oracle EM on the same counts."""
+    from seekmer_amd import infer
+    rng = np.random.default_rng(8)
+    n_tx, n_classes = 120, 500
+    sizes = rng.integers(1, 5, n_classes)
+    cls = np.repeat(np.arange(n_classes), sizes)
+    tx = rng.integers(0, n_tx, cls.size)
+    class_map = np.vstack([cls, tx]).astype(np.int64)
+    class_count = rng.integers(1, 4000, n_classes).astype('f8')
+    l = rng.uniform(100, 2000, n_tx)
+    offsets, targets = infer._csr_from_class_map(class_map, n_classes)
+    quant = infer._QuantHandle.from_csr(n_tx, offsets, targets, class_count)
+    x0 = 1.0 / l
+    x0 /= x0.sum()
+    n_boot = 40
+    out, counts, iters = quant.bootstrap(n_boot, 1234, x0, l, want_counts=True)
+    out2, counts2, _ = quant.bootstrap(n_boot, 1234, x0, l, want_counts=True)
+    quant.close()
+    np.testing.assert_array_equal(counts, counts2)      # seeded: reproducible
+    np.testing.assert_array_equal(out, out2)
+    n = class_count.sum()
+    assert (counts.sum(axis=1) == n).all()
+    p = class_count / n
+    mean = counts.mean(axis=0)
+    sigma = np.sqrt(n * p * (1 - p) / n_boot)
+    assert (np.abs(mean - n * p) < 6 * sigma + 1).all()
+    assert len({c.tobytes() for c in counts}) == n_boot   # replicates differ
+    for b in (0, n_boot - 1):
+        x_ref, it_ref = oracle.em(x0, l, class_map, counts[b].astype('f8'))
+        assert it_ref == iters[b]
+        np.testing.assert_allclose(out[b], x_ref, rtol=1e-8, atol=1e-300)
