@@ -390,7 +390,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(m->unit_offset.ensure(n_units));
     SKM_TRY(m->unit_slot.ensure(n_units));
     SKM_TRY(m->unit_key.ensure(n_units));
-    SKM_TRY(m->unit_entries.ensure(std::max<size_t>((size_t)n_units * 8, 1 << 16)));
+
     SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
 
     // launch geometry: at most 6 blocks of 256 lanes per CU (the kernel's
@@ -402,6 +402,8 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, ws_budget / (per_thread * 256)));
     m->grid_blocks = (int)blocks;
     SKM_TRY(m->workspace.ensure((size_t)(blocks * 256) * regions * ix->d.max_target_count));
+    // entry arena: ~8 ids per unit plus one 2048-id slice of slack per wave
+    SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * 4 * 2048 + 4096));
 
     MapBatch b{};
     b.codes = m->codes.p;
@@ -444,7 +446,6 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         unsigned long long st[16];
         HIP_TRY(hipMemcpy(st, b.stats, sizeof(st), hipMemcpyDeviceToHost));
         for (int i = 0; i < 16; ++i) m->stats_total[i] += st[i];
-        m->stats_total[9] += ids;
     }
 
     // class counting
@@ -554,7 +555,7 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     const int64_t n = m->last_units;
-    if (n_entries) *n_entries = m->last_ids;
+    if (n_entries) *n_entries = 0;
     if (n == 0) return SKM_OK;
     if (begin) HIP_TRY(hipMemcpy(begin, m->unit_begin.p, n * 4, hipMemcpyDeviceToHost));
     if (end) HIP_TRY(hipMemcpy(end, m->unit_end.p, n * 4, hipMemcpyDeviceToHost));
@@ -566,11 +567,13 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
             if (anchor_offset) anchor_offset[i] = a[i].offset;
         }
     }
-    std::vector<int32_t> cnt;
-    if (counts || entries) {
-        cnt.resize(n);
-        HIP_TRY(hipMemcpy(cnt.data(), m->unit_count.p, n * 4, hipMemcpyDeviceToHost));
-        if (counts) memcpy(counts, cnt.data(), n * 4);
+    std::vector<int32_t> cnt(n);
+    HIP_TRY(hipMemcpy(cnt.data(), m->unit_count.p, n * 4, hipMemcpyDeviceToHost));
+    if (counts) memcpy(counts, cnt.data(), n * 4);
+    if (n_entries) {
+        int64_t total = 0;
+        for (int64_t u = 0; u < n; ++u) total += cnt[u];
+        *n_entries = total;           // the arena itself has per-wave slack
     }
     if (entries) {
         std::vector<int64_t> off(n);

@@ -1,5 +1,5 @@
 // Pseudoalignment kernels for gfx950: read packing and the contig-jumping
-// mapper (one read or read pair per lane, 64 units per wavefront).
+// mapper (one read or read pair per lane at a time, lanes refilled as they finish).
 //
 // What is computed is the reference's per-read state machine
 // (/root/reference/seekmer/_mapper.pyx:111-343, 350-501) -- every branch is
@@ -196,29 +196,6 @@ __device__ __forceinline__ int sift4_right(uint32_t ref8, const ReadView &r, int
     return 0;
 }
 
-// _find_first_kmer, _mapper.pyx:199-216
-template <bool STATS>
-__device__ __forceinline__ void find_first_kmer(const DevIndex &ix, const ReadView &r,
-                                                const TList &list, Span &span, LaneStats *st)
-{
-    uint64_t kmer = read_kmer(r, span.begin);
-    span.anchor = map_kmer<STATS>(ix, kmer, st);
-    if (span.anchor.offset >= 0) {
-        span.end = span.begin;
-        map_contig<STATS>(ix, span.anchor, list, span, st);
-        return;
-    }
-    for (int i = span.begin + K; i < r.len; ++i) {
-        kmer = ((kmer << 2) | read_code(r, i)) & KMER_MASK;        // _kmer.append
-        span.anchor = map_kmer<STATS>(ix, kmer, st);
-        if (span.anchor.offset < 0) continue;
-        span.begin = i + 1 - K;
-        span.end = span.begin;
-        map_contig<STATS>(ix, span.anchor, list, span, st);
-        return;
-    }
-}
-
 __device__ __forceinline__ int left_move(const DevIndex &ix, Coord a)
 {
     const bool forward = a.entry >= 0;
@@ -230,105 +207,6 @@ __device__ __forceinline__ int right_move(const DevIndex &ix, Coord a)
     const bool forward = a.entry >= 0;
     const int32_t contig = forward ? a.entry : ~a.entry;
     return forward ? (int)ix.contigs[contig].length - a.offset - K : a.offset;
-}
-
-// _filter_targets_to_left, _mapper.pyx:222-275
-template <bool STATS>
-__device__ __forceinline__ void filter_left(const DevIndex &ix, const ReadView &r, const TList &list,
-                                            Span &span, LaneStats *st)
-{
-    bool forward = span.anchor.entry >= 0;
-    int move = left_move(ix, span.anchor);
-    if (STATS) st->contig_reads++;
-    while (span.begin > move) {
-        span.begin -= move;
-        span.anchor.offset -= forward ? move : -move;
-        int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, st), r, span.begin);
-        if (shift == INVALID_SHIFT || shift + 1 + move <= 0) { span.n = 0; return; }
-        span.begin -= shift + 1;
-        if (span.begin < 0) { span.begin = 0; return; }
-        // _kmer.prepend(get_tail_kmer(anchor), read[begin])
-        uint64_t kmer = (tail_kmer<STATS>(ix, span.anchor, st) >> 2)
-                        | ((uint64_t)read_code(r, span.begin) << (2 * K - 2));
-        span.anchor = map_kmer<STATS>(ix, kmer, st);
-        if (!(span.anchor.offset >= 0) || !filter_on_contig<STATS>(ix, list, span, st)) {
-            if (span.begin < K) { span.begin = 0; return; }
-            span.begin -= K;
-            kmer = read_kmer(r, span.begin);
-            span.anchor = map_kmer<STATS>(ix, kmer, st);
-            if (!(span.anchor.offset >= 0) || !filter_on_contig<STATS>(ix, list, span, st)) {
-                span.n = 0;
-                return;
-            }
-        }
-        forward = span.anchor.entry >= 0;
-        move = left_move(ix, span.anchor);
-        if (STATS) st->contig_reads++;
-    }
-    span.anchor.offset -= forward ? span.begin : -span.begin;
-    if (sift4_left(contig8<STATS>(ix, span.anchor, true, st), r, 0) == INVALID_SHIFT) span.n = 0;
-}
-
-// _filter_targets_to_right, _mapper.pyx:281-343 (lines 316-329 are dead code)
-template <bool STATS>
-__device__ __forceinline__ void filter_right(const DevIndex &ix, const ReadView &r, const TList &list,
-                                             Span &span, LaneStats *st)
-{
-    span.anchor = map_kmer<STATS>(ix, read_kmer(r, span.end), st);
-    bool forward = span.anchor.entry >= 0;
-    int move = right_move(ix, span.anchor);
-    if (STATS) st->contig_reads++;
-    while (r.len - span.end - K > move) {
-        span.end += move;
-        span.anchor.offset += forward ? move : -move;
-        int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, st), r,
-                                span.end + K - ALIGN_LENGTH);
-        if (shift == INVALID_SHIFT || shift + 1 + move <= 0) { span.n = 0; return; }
-        span.end += shift + 1;
-        if (span.end + K > r.len) { span.end = r.len - K; return; }
-        // _kmer.append(get_tail_kmer(anchor), read[end + k - 1])
-        uint64_t kmer = ((tail_kmer<STATS>(ix, span.anchor, st) << 2)
-                         | read_code(r, span.end + K - 1)) & KMER_MASK;
-        span.anchor = map_kmer<STATS>(ix, kmer, st);
-        if (!(span.anchor.offset >= 0) || !filter_on_contig<STATS>(ix, list, span, st)) {
-            span.n = 0;
-            return;
-        }
-        forward = span.anchor.entry >= 0;
-        move = right_move(ix, span.anchor);
-        if (STATS) st->contig_reads++;
-    }
-    const int rest = r.len - span.end - K;
-    span.anchor.offset += forward ? rest : -rest;
-    if (sift4_right(contig8<STATS>(ix, span.anchor, false, st), r, r.len - ALIGN_LENGTH)
-            == INVALID_SHIFT)
-        span.n = 0;
-}
-
-// map_read, _mapper.pyx:151-193.  Reads shorter than k (undefined behaviour in
-// the reference) are reported unmapped with the initial span.
-template <bool STATS>
-__device__ __forceinline__ Span map_read(const DevIndex &ix, const ReadView &r, const TList &list,
-                                      LaneStats *st)
-{
-    Span span;
-    span.anchor = invalid_coord();
-    span.begin = 0;
-    span.end = 0;
-    span.n = 0;
-    if (r.len < K) return span;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        find_first_kmer<STATS>(ix, r, list, span, st);
-        if (span.n == 0) return span;
-        if (span.begin > 0) filter_left<STATS>(ix, r, list, span, st);
-        if (span.n != 0 && span.end < r.len - K) filter_right<STATS>(ix, r, list, span, st);
-        if (span.n != 0 || attempt == 1) return span;
-        span.anchor = invalid_coord();                    // single retry, lines 179-184
-        span.begin += K;
-        if (span.begin + K > r.len) span.begin = r.len - K;
-        span.end = span.begin;
-    }
-    return span;
 }
 
 // _intersect, _mapper.pyx:350-397
@@ -359,6 +237,26 @@ __device__ __forceinline__ uint64_t tuple_key_step(uint64_t h, uint32_t id)
     return h;
 }
 
+// The reference maps a read with nested loops (map_read -> _find_first_kmer /
+// _filter_targets_to_left / _filter_targets_to_right, _mapper.pyx:151-343).
+// On a 64-wide wave that shape is ruinous: the 200-instruction hash sits at
+// seven call sites and the whole wave idles while a few lanes roll their
+// first k-mer past a sequencing error or take the single retry.  Here every
+// lane runs the SAME state machine, but explicitly: one round = at most one
+// index lookup per lane at ONE call site, one list merge site, one SIFT4 site
+// per direction; a lane that finishes its unit is refilled at once from its
+// wave's private unit range, so all 64 lanes keep doing useful lookups.
+// States that wait for a lookup result:
+//   Y_FIRST  first-hit scan (_find_first_kmer)            Y_RA  right re-anchor (:283-284)
+//   Y_LJ/Y_LS left junction / skip-a-k lookup (:247-263)  Y_RJ  right junction (:309-315)
+// States that run without a lookup:
+//   N_LEFT (:229-246, :270-275)  N_RIGHT_ENTER (:174-176)  N_RIGHT (:285-308, :335-343)
+//   N_AFTER (:177-193)  N_MATE_DONE  UNIT_DONE (map_read_pair :129-144 + batch loop :89-94)
+enum : int { ST_IDLE = 0, Y_FIRST, Y_LJ, Y_LS, Y_RA, Y_RJ, N_LEFT, N_RIGHT_ENTER, N_RIGHT, N_AFTER,
+             N_MATE_DONE, ST_UNIT_DONE };
+
+constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
+
 template <bool STATS>
 __global__ void __launch_bounds__(256)
 map_units_kernel(DevIndex ix, MapBatch b)
@@ -371,33 +269,214 @@ map_units_kernel(DevIndex ix, MapBatch b)
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const size_t stride = (size_t)total_threads;
-    const TList list1{b.workspace + gtid, stride};
-    const TList list2{b.workspace + (size_t)ix.max_target_count * stride + gtid, stride};
+    int32_t *const ws1 = b.workspace + gtid;
+    int32_t *const ws2 = ws1 + (size_t)ix.max_target_count * stride;
     LaneStats ls = {0, 0, 0, 0, 0, 0, 0};
-    uint64_t read_bases = 0, n_reads = 0;
+    uint64_t read_bases = 0, n_reads = 0, tuple_ids = 0;
 
-    // all 64 lanes of a wave run the same trip count (wave-wide scan below)
-    for (int64_t first = gtid - lane; first < b.n_units; first += total_threads) {
-        const int64_t u = first + lane;
-        const bool active = u < b.n_units;
-        Span s1, s2;
-        s1.begin = 0; s1.end = 0; s1.n = 0; s1.anchor = invalid_coord();
-        s2 = s1;
-        if (active) {
-            const int64_t r1 = b.paired ? 2 * u : u;
-            int len1 = 0, len2 = 0;
-            const int mates = b.paired ? 2 : 1;
-            for (int m = 0; m < mates; ++m) {          // single inlined copy of the state machine
-                const int64_t r = r1 + m;
-                ReadView v{b.codes + r * b.words_per_read, b.acgt + r * b.words_per_read,
-                           (int)(b.offsets[r + 1] - b.offsets[r])};
-                const Span s = map_read<STATS>(ix, v, m ? list2 : list1, &ls);
-                if (STATS) { read_bases += v.len; n_reads++; }
-                if (m == 0) { s1 = s; len1 = v.len; } else { s2 = s; len2 = v.len; }
+    // this wave's private range of units: no atomics for work distribution
+    const int64_t n_waves = total_threads >> 6;
+    const int64_t per_wave = (b.n_units + n_waves - 1) / n_waves;
+    int64_t next = (gtid >> 6) * per_wave;
+    const int64_t limit = min(b.n_units, next + per_wave);
+    int64_t chunk_pos = 0, chunk_end = 0;      // wave-uniform slice of the entry arena
+
+    // per-lane machine state
+    int state = ST_IDLE;
+    int64_t u = 0;
+    int mate = 0, attempt = 0, scan_i = 0, len1 = 0;
+    uint64_t kmer = 0;
+    ReadView rv{b.codes, b.acgt, 0};
+    Span span{0, 0, invalid_coord(), 0};
+    Span s1 = span;
+
+    for (;;) {
+        // ---------------------------------------------------------- refill
+        const unsigned long long idle = __ballot(state == ST_IDLE);
+        if (idle != 0 && next < limit) {
+            const int rank = __popcll(idle & ((1ULL << lane) - 1));
+            if (state == ST_IDLE && next + rank < limit) {
+                u = next + rank;
+                mate = 0;
+                attempt = 0;
+                const int64_t r = b.paired ? 2 * u : u;
+                rv.codes = b.codes + r * b.words_per_read;
+                rv.acgt = b.acgt + r * b.words_per_read;
+                rv.len = (int)(b.offsets[r + 1] - b.offsets[r]);
+                span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
+                if (STATS) { read_bases += rv.len; n_reads++; }
+                if (rv.len < K) {
+                    state = N_MATE_DONE;              // shorter than k: unmapped (documented deviation)
+                } else {
+                    kmer = read_kmer(rv, 0);
+                    scan_i = K;
+                    state = Y_FIRST;
+                }
             }
+            next += __popcll(idle);
+        }
+        if (__ballot(state != ST_IDLE) == 0) break;
+
+        const TList list{mate ? ws2 : ws1, stride};
+
+        // ------------------------------------------ the one index lookup site
+        Coord pos = invalid_coord();
+        if (state >= Y_FIRST && state <= Y_RJ) pos = map_kmer<STATS>(ix, kmer, &ls);
+
+        // _find_first_kmer, _mapper.pyx:199-216
+        if (state == Y_FIRST) {
+            span.anchor = pos;
+            if (pos.offset >= 0) {
+                span.begin = scan_i - K;
+                span.end = span.begin;
+                map_contig<STATS>(ix, pos, list, span, &ls);
+                state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+            } else if (scan_i < rv.len) {
+                kmer = ((kmer << 2) | read_code(rv, scan_i)) & KMER_MASK;     // _kmer.append
+                ++scan_i;
+            } else {
+                state = N_MATE_DONE;                  // no hit: returned as is, no retry (:170-171, :186-187)
+            }
+        } else if (state == Y_RA) {
+            span.anchor = pos;
+            state = N_RIGHT;
+        } else if (state == Y_LJ || state == Y_LS || state == Y_RJ) {
+            // the one merge site: `anchor = map_kmer(...)`, then _filter_on_contig
+            span.anchor = pos;
+            const bool ok = pos.offset >= 0 && filter_on_contig<STATS>(ix, list, span, &ls);
+            if (state == Y_LJ) {
+                if (ok) state = N_LEFT;
+                else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }      // :252-256
+                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; } // :257-259
+            } else if (state == Y_LS) {
+                if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }             // :260-263
+            } else {
+                if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }            // :312-315
+            }
+        }
+
+        // ------------------------------------------ run until the next lookup
+        while (__ballot(state >= N_LEFT && state <= N_MATE_DONE) != 0) {
+            if (state == N_LEFT) {
+                // _filter_targets_to_left loop head + body up to the junction k-mer,
+                // or the closing 8-base check once the read no longer passes the edge
+                const bool forward = span.anchor.entry >= 0;
+                const int move = left_move(ix, span.anchor);
+                if (STATS) ls.contig_reads++;
+                const bool in_loop = span.begin > move;
+                int at;
+                if (in_loop) {
+                    span.begin -= move;
+                    span.anchor.offset -= forward ? move : -move;
+                    at = span.begin;
+                } else {
+                    span.anchor.offset -= forward ? span.begin : -span.begin;
+                    at = 0;
+                }
+                const int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
+                if (!in_loop) {
+                    if (shift == INVALID_SHIFT) span.n = 0;
+                    state = N_RIGHT_ENTER;
+                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                    span.n = 0;
+                    state = N_AFTER;
+                } else {
+                    span.begin -= shift + 1;
+                    if (span.begin < 0) {
+                        span.begin = 0;
+                        state = N_RIGHT_ENTER;
+                    } else {
+                        kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)      // _kmer.prepend
+                               | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
+                        state = Y_LJ;
+                    }
+                }
+            } else if (state == N_RIGHT_ENTER) {
+                if (span.n != 0 && span.end < rv.len - K) {
+                    kmer = read_kmer(rv, span.end);
+                    state = Y_RA;
+                } else {
+                    state = N_AFTER;
+                }
+            } else if (state == N_RIGHT) {
+                const bool forward = span.anchor.entry >= 0;
+                const int move = right_move(ix, span.anchor);
+                if (STATS) ls.contig_reads++;
+                const int rest = rv.len - span.end - K;
+                const bool in_loop = rest > move;
+                int at;
+                if (in_loop) {
+                    span.end += move;
+                    span.anchor.offset += forward ? move : -move;
+                    at = span.end + K - ALIGN_LENGTH;
+                } else {
+                    span.anchor.offset += forward ? rest : -rest;
+                    at = rv.len - ALIGN_LENGTH;
+                }
+                const int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
+                if (!in_loop) {
+                    if (shift == INVALID_SHIFT) span.n = 0;
+                    state = N_AFTER;
+                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                    span.n = 0;
+                    state = N_AFTER;
+                } else {
+                    span.end += shift + 1;
+                    if (span.end + K > rv.len) {
+                        span.end = rv.len - K;
+                        state = N_AFTER;
+                    } else {
+                        kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)      // _kmer.append
+                                | read_code(rv, span.end + K - 1)) & KMER_MASK;
+                        state = Y_RJ;
+                    }
+                }
+            } else if (state == N_AFTER) {
+                if (span.n != 0 || attempt == 1) {
+                    state = N_MATE_DONE;
+                } else {                                  // the single retry, :179-185
+                    attempt = 1;
+                    span.anchor = invalid_coord();
+                    span.begin += K;
+                    if (span.begin + K > rv.len) span.begin = rv.len - K;
+                    span.end = span.begin;
+                    kmer = read_kmer(rv, span.begin);
+                    scan_i = span.begin + K;
+                    state = Y_FIRST;
+                }
+            } else if (state == N_MATE_DONE) {
+                if (b.paired && mate == 0) {
+                    s1 = span;
+                    len1 = rv.len;
+                    mate = 1;
+                    attempt = 0;
+                    const int64_t r = 2 * u + 1;
+                    rv.codes = b.codes + r * b.words_per_read;
+                    rv.acgt = b.acgt + r * b.words_per_read;
+                    rv.len = (int)(b.offsets[r + 1] - b.offsets[r]);
+                    span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
+                    if (STATS) { read_bases += rv.len; n_reads++; }
+                    if (rv.len >= K) {
+                        kmer = read_kmer(rv, 0);
+                        scan_i = K;
+                        state = Y_FIRST;
+                    }                                     // else: stays N_MATE_DONE, closed next pass
+                } else {
+                    state = ST_UNIT_DONE;
+                }
+            }
+        }
+
+        // --------------------------------------------------- finished units
+        const unsigned long long done = __ballot(state == ST_UNIT_DONE);
+        if (done == 0) continue;
+        int n_out = 0;
+        if (state == ST_UNIT_DONE) {
             if (b.paired) {
-                // map_read_pair, _mapper.pyx:111-145
-                if (!intersect(list1, s1, list2, s2)) {
+                // map_read_pair, _mapper.pyx:129-144 (span = mate 2, s1 = mate 1)
+                const TList l1{ws1, stride}, l2{ws2, stride};
+                const Span s2 = span;
+                if (!intersect(l1, s1, l2, s2)) {
                     s1.n = 0;
                     s1.begin = 0;
                     s1.end = -K;
@@ -405,50 +484,55 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     s1.begin = 0;
                     s1.end = -K;
                 } else {
-                    s1.end = len1 - K;
-                    s2.end = len2 - K;
                     int interval = s2.anchor.offset - s1.anchor.offset;
                     if (s1.anchor.entry < 0) interval = -interval;
-                    s1.end += interval + s2.end - s2.begin;
+                    s1.end = (len1 - K) + interval + (rv.len - K) - s2.begin;
                 }
+                span = s1;
             }
             // fragment length rule, _mapper.pyx:90-94
-            int length = s1.end - s1.begin + K;
+            int length = span.end - span.begin + K;
             if (length > 0) {
                 if (length >= MAX_FRAGMENT_LENGTH) length = MAX_FRAGMENT_LENGTH - 1;
                 atomicAdd(&fld_lds[length], 1u);
             }
+            n_out = span.n;
         }
-        // one arena allocation per wave: exclusive scan of the list lengths
-        int n = active ? s1.n : 0;
-        int scan = n;
+        // one slice of the entry arena for all lanes that finished this round
+        int scan = n_out;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(scan, d, 64);
             if (lane >= d) scan += up;
         }
         const int wave_total = __shfl(scan, 63, 64);
-        unsigned long long wave_base = 0;
-        if (lane == 63 && wave_total > 0)
-            wave_base = atomicAdd(b.ids_cursor, (unsigned long long)wave_total);
-        wave_base = __shfl(wave_base, 63, 64);
-        if (active) {
-            const int64_t off = (int64_t)wave_base + scan - n;
-            uint64_t key = 0x243F6A8885A308D3ULL ^ (uint64_t)n;
-            const bool fits = off + n <= b.ids_capacity;
-            for (int i = 0; i < n; ++i) {
-                const int32_t e = list1.get(i);
+        if (chunk_pos + wave_total > chunk_end) {
+            const int64_t want = wave_total > ARENA_CHUNK ? wave_total : ARENA_CHUNK;
+            unsigned long long got = 0;
+            if (lane == 0) got = atomicAdd(b.ids_cursor, (unsigned long long)want);
+            chunk_pos = (int64_t)__shfl(got, 0, 64);
+            chunk_end = chunk_pos + want;
+        }
+        if (state == ST_UNIT_DONE) {
+            const int64_t off = chunk_pos + scan - n_out;
+            uint64_t key = 0x243F6A8885A308D3ULL ^ (uint64_t)n_out;
+            const bool fits = off + n_out <= b.ids_capacity;
+            for (int i = 0; i < n_out; ++i) {
+                const int32_t e = ws1[(size_t)i * stride];
                 if (fits) b.unit_entries[off + i] = e;
                 key = tuple_key_step(key, (uint32_t)(e < 0 ? ~e : e));   // _get_ids, :533-536
             }
             if (key == 0) key = 1;
             b.unit_offset[u] = off;
-            b.unit_count[u] = n;
-            b.unit_key[u] = n ? key : 0;
-            b.unit_begin[u] = s1.begin;
-            b.unit_end[u] = s1.end;
-            b.unit_anchor[u] = s1.anchor;
+            b.unit_count[u] = n_out;
+            b.unit_key[u] = n_out ? key : 0;
+            b.unit_begin[u] = span.begin;
+            b.unit_end[u] = span.end;
+            b.unit_anchor[u] = span.anchor;
+            if (STATS) tuple_ids += n_out;
+            state = ST_IDLE;
         }
+        chunk_pos += wave_total;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x)
@@ -464,6 +548,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
         atomicAdd(&o[6], (unsigned long long)ls.targets_merged);
         atomicAdd(&o[7], (unsigned long long)ls.seq_fetches);
         atomicAdd(&o[8], (unsigned long long)ls.merges);
+        atomicAdd(&o[9], (unsigned long long)tuple_ids);
     }
 }
 
