@@ -126,9 +126,10 @@ int skm_mapper_timing(skm_mapper *mapper, double stats[8]);
  * algorithmic bytes): enable, map, then read.  out[0]=reads
  * [1]=read bases [2]=lookups [3]=slots probed [4]=ContigEntry reads [5]=target
  * entries copied [6]=target entries merged [7]=8-base fetches [8]=merges
- * [9]=tuple ids. */
+ * [9]=tuple ids; out[16..28] = scheduler census of the map kernel: rounds, then
+ * (executions, lanes) of lookup, copy, merge, left, right, emit. */
 int skm_mapper_set_stats(skm_mapper *mapper, int enable);
-int skm_mapper_access_stats(skm_mapper *mapper, int64_t out[16]);
+int skm_mapper_access_stats(skm_mapper *mapper, int64_t out[32]);
 
 /* ------------------------------------------------------------ quantification
  * MapResult.effective_lengths (seekmer/mapper.py:134-141). */

@@ -3,6 +3,7 @@
 // No torch types, no exceptions across the boundary.
 #include "../../include/seekmer_hip.h"
 #include "skm_kernels.h"
+#include "skm_pool.h"
 
 #include <dlfcn.h>
 #include <algorithm>
@@ -55,19 +56,20 @@ struct DBuf {
         if (n <= cap) return SKM_OK;
         size_t want = std::max(n, cap + cap / 2);
         T *q = nullptr;
-        HIP_TRY(hipMalloc((void **)&q, want * sizeof(T)));
+        HIP_TRY(pool_alloc((void **)&q, want * sizeof(T)));
+        want = pool_round(want * sizeof(T)) / sizeof(T);
         if (keep && p && cap) {
             HIP_TRY(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream));
             HIP_TRY(hipStreamSynchronize(stream));
         }
-        if (p) HIP_TRY(hipFree(p));
+        pool_free(p);
         p = q;
         cap = want;
         return SKM_OK;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        pool_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -100,6 +102,7 @@ struct skm_mapper {
     DBuf<ClassSlot> slots;
     DBuf<int32_t> arena_len;
     DBuf<int32_t> arena;
+    DBuf<int64_t> class_list;
     DBuf<unsigned long long> counters;   // [0]=arena_cursor [1]=n_classes [2]=n_unaligned [3]=n_units [8..2007]=fld
     DBuf<int> error;
     // batch buffers
@@ -120,7 +123,8 @@ struct skm_mapper {
     int64_t host_classes = 0, host_arena_used = 0;
     bool want_stats = false;
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
-    unsigned long long stats_total[16] = {0};
+    unsigned long long stats_total[32] = {0};
+    int vote[8] = {32, 16, 16, 16, 16, 0, 0, 0};   // quorum per action of the map kernel's scheduler
 };
 
 struct skm_quant {
@@ -296,9 +300,10 @@ extern "C" int skm_index_info(const skm_index *ix, int64_t info[6])
 // ------------------------------------------------------------------- mapper
 namespace {
 
-constexpr int CTR_ARENA = 0, CTR_CLASSES = 1, CTR_UNALIGNED = 2, CTR_UNITS = 3, CTR_FLD = 8;
+constexpr int CTR_ARENA = 0, CTR_CLASSES = 1, CTR_UNALIGNED = 2, CTR_UNITS = 3, CTR_LISTED = 4,
+              CTR_DEFERRED = 5, CTR_FLD = 8;
 constexpr int CTR_WORDS = 8 + MAX_FRAGMENT_LENGTH;
-constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2064;
+constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2080;
 
 void bind_table(skm_mapper *m, uint64_t n_slots)
 {
@@ -312,6 +317,10 @@ void bind_table(skm_mapper *m, uint64_t n_slots)
     m->t.n_unaligned = m->counters.p + CTR_UNALIGNED;
     m->t.n_units = m->counters.p + CTR_UNITS;
     m->t.global_fld = m->counters.p + CTR_FLD;
+    m->t.class_list = m->class_list.p;
+    m->t.class_list_capacity = (int64_t)m->class_list.cap;
+    m->t.n_listed = m->counters.p + CTR_LISTED;
+    m->t.n_deferred = m->counters.p + CTR_DEFERRED;
     m->t.error = m->error.p;
 }
 
@@ -320,6 +329,7 @@ int table_reset(skm_mapper *m, uint64_t n_slots)
     SKM_TRY(m->slots.ensure(n_slots));
     SKM_TRY(m->arena_len.ensure(n_slots));
     SKM_TRY(m->arena.ensure(1 << 20));
+    SKM_TRY(m->class_list.ensure(1 << 16));
     SKM_TRY(m->counters.ensure(CTR_WORDS));
     SKM_TRY(m->error.ensure(1));
     HIP_TRY(hipMemsetAsync(m->counters.p, 0, CTR_WORDS * sizeof(unsigned long long), m->stream));
@@ -333,30 +343,55 @@ int table_reset(skm_mapper *m, uint64_t n_slots)
     return SKM_OK;
 }
 
-// grow the class table so that `extra` more classes keep the load below 0.7
-int table_reserve(skm_mapper *m, int64_t extra)
+// make the class table at least `want_slots` big (power of two), moving its
+// entries; the registry (and, for a batch in flight, the unit -> slot map) is
+// redirected through a forwarding array
+int table_grow(skm_mapper *m, uint64_t want_slots, int64_t units_in_flight)
 {
     uint64_t n_slots = m->t.slot_mask + 1;
     uint64_t need = n_slots;
-    while ((double)(m->host_classes + extra) > 0.7 * (double)need) need <<= 1;
+    while (need < want_slots) need <<= 1;
     if (need == n_slots) return SKM_OK;
     DBuf<ClassSlot> new_slots;
     DBuf<int32_t> new_len;
+    DBuf<int64_t> forward;
     SKM_TRY(new_slots.ensure(need));
     SKM_TRY(new_len.ensure(need));
+    SKM_TRY(forward.ensure(n_slots));
     ClassTable to = m->t;
     to.slots = new_slots.p;
     to.arena_len = new_len.p;
     to.slot_mask = need - 1;
     launch_class_init(to, m->stream);
-    launch_class_rehash(m->t, to, m->stream);
+    launch_class_rehash(m->t, to, forward.p, m->stream);
+    unsigned long long listed = 0;
+    HIP_TRY(hipMemcpyAsync(&listed, m->counters.p + CTR_LISTED, 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    launch_slot_remap(m->class_list.p, (int64_t)listed, forward.p, m->stream);
+    launch_slot_remap(m->unit_slot.p, units_in_flight, forward.p, m->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->slots.release();
     m->arena_len.release();
+    forward.release();
     m->slots = new_slots;
     m->arena_len = new_len;
     bind_table(m, need);
+    return SKM_OK;
+}
+
+// Size the table for a batch of `n_units`: classes are far fewer than units in
+// practice (0.09 per pair at 10 M pairs), so reserve for one new class per 8
+// units at load <= 0.5 and let the bounded probe defer the rest.
+int table_reserve(skm_mapper *m, int64_t n_units)
+{
+    const double expect = (double)m->host_classes + (double)n_units / 8.0 + 1024.0;
+    uint64_t want = 1 << 16;
+    while ((double)want * 0.5 < expect) want <<= 1;
+    SKM_TRY(table_grow(m, want, 0));
+    // registry and arena can never need more than one entry per unit / id of the batch
+    SKM_TRY(m->class_list.ensure((size_t)(m->host_classes + n_units + 1024), true, m->stream));
+    bind_table(m, m->t.slot_mask + 1);
     return SKM_OK;
 }
 
@@ -422,6 +457,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     b.ids_cursor = m->batch_ctl.p + BC_IDS;
     b.fld = m->batch_ctl.p + BC_FLD;
     b.stats = m->batch_ctl.p + BC_STATS;
+    for (int i = 0; i < 8; ++i) b.vote[i] = m->vote[i];
 
     HIP_TRY(hipEventRecord(m->ev[0], m->stream));
     launch_pack_reads(d_bases, d_offsets, n_reads, words, m->codes.p, m->acgt.p, m->stream);
@@ -443,24 +479,41 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     }
     m->last_ids = (int64_t)ids;
     if (m->want_stats) {
-        unsigned long long st[16];
+        unsigned long long st[32];
         HIP_TRY(hipMemcpy(st, b.stats, sizeof(st), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 16; ++i) m->stats_total[i] += st[i];
+        for (int i = 0; i < 32; ++i) m->stats_total[i] += st[i];
     }
 
     // class counting
     SKM_TRY(table_reserve(m, n_units));
     SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)ids + 1024), true, m->stream));
     bind_table(m, m->t.slot_mask + 1);
-    launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, m->stream);
+    for (int pass = 0;; ++pass) {
+        HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
+        launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, pass > 0, m->stream);
+        HIP_TRY(hipGetLastError());
+        unsigned long long ctr[8];
+        HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (ctr[CTR_DEFERRED] == 0) break;
+        if (pass > 40) return fail(SKM_ERR_STATE, "class table cannot absorb the batch");
+        // too full for bounded probing: grow 4x (classes claimed so far move along), retry the rest
+        SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 4, n_units));
+    }
     launch_class_verify_commit(m->t, b, m->units_done, m->unit_slot.p, m->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev[3], m->stream));
-    unsigned long long ctr[4];
+    unsigned long long ctr[8];
     HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
     SKM_TRY(read_error(m));
     m->host_arena_used = (int64_t)ctr[CTR_ARENA];
     m->host_classes = (int64_t)ctr[CTR_CLASSES];
+    if (ctr[CTR_LISTED] != ctr[CTR_CLASSES])
+        return fail(SKM_ERR_STATE, "class registry out of step (%llu listed, %llu classes)",
+                    ctr[CTR_LISTED], ctr[CTR_CLASSES]);
+    // keep the load below 0.5 for the next batch
+    if ((uint64_t)m->host_classes * 2 > m->t.slot_mask + 1)
+        SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 2, 0));
     m->units_done += n_units;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->t_pack_ns += ms * 1e6;
@@ -478,9 +531,11 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     SKM_TRY(set_device(ix->device));
     skm_mapper *m = new skm_mapper();
     m->ix = ix;
-    HIP_TRY(hipStreamCreate(&m->stream));
+    HIP_TRY(pool_stream_acquire(&m->stream));
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
     m->want_stats = getenv("SKM_MAP_STATS") != nullptr;
+    if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "lookup,copy,merge,align,emit"
+        sscanf(v, "%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4]);
     int rc = table_reset(m, 1 << 16);
     if (rc != SKM_OK) { delete m; return rc; }
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -493,13 +548,14 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     if (!m) return SKM_OK;
     (void)hipSetDevice(m->ix->device);
     (void)hipStreamSynchronize(m->stream);
-    m->slots.release(); m->arena_len.release(); m->arena.release(); m->counters.release();
+    m->slots.release(); m->arena_len.release(); m->arena.release(); m->class_list.release();
+    m->counters.release();
     m->error.release(); m->bases.release(); m->offsets.release(); m->codes.release();
     m->acgt.release(); m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
     m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
     m->unit_slot.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(m->stream);
+    pool_stream_release(m->stream);
     delete m;
     return SKM_OK;
 }
@@ -617,24 +673,21 @@ extern "C" int skm_mapper_export(skm_mapper *m, int64_t *class_offsets, int32_t 
     const int64_t C = m->host_classes, M = m->host_arena_used;
     if (class_offsets) class_offsets[0] = 0;
     if (C == 0) return SKM_OK;
-    DBuf<int64_t> d_off; DBuf<int32_t> d_len; DBuf<double> d_cnt; DBuf<unsigned long long> d_fs, d_cur;
-    SKM_TRY(d_off.ensure(C)); SKM_TRY(d_len.ensure(C)); SKM_TRY(d_cnt.ensure(C));
-    SKM_TRY(d_fs.ensure(C)); SKM_TRY(d_cur.ensure(1));
-    HIP_TRY(hipMemsetAsync(d_cur.p, 0, 8, m->stream));
-    launch_class_compact(m->t, d_off.p, d_len.p, d_cnt.p, d_fs.p, d_cur.p, m->stream);
+    DBuf<int64_t> d_off, d_len; DBuf<double> d_cnt; DBuf<unsigned long long> d_fs;
+    SKM_TRY(d_off.ensure(C)); SKM_TRY(d_len.ensure(C)); SKM_TRY(d_cnt.ensure(C)); SKM_TRY(d_fs.ensure(C));
+    launch_class_compact(m->t, C, d_off.p, d_len.p, d_cnt.p, d_fs.p, m->stream);
     HIP_TRY(hipGetLastError());
-    std::vector<int64_t> off(C);
-    std::vector<int32_t> len(C);
+    std::vector<int64_t> off(C), len(C);
     std::vector<double> cnt(C);
     std::vector<unsigned long long> fs(C);
     std::vector<int32_t> arena((size_t)std::max<int64_t>(M, 1));
     HIP_TRY(hipMemcpyAsync(off.data(), d_off.p, C * 8, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(len.data(), d_len.p, C * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(len.data(), d_len.p, C * 8, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt.p, C * 8, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipMemcpyAsync(fs.data(), d_fs.p, C * 8, hipMemcpyDeviceToHost, m->stream));
     if (M) HIP_TRY(hipMemcpyAsync(arena.data(), m->arena.p, (size_t)M * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    d_off.release(); d_len.release(); d_cnt.release(); d_fs.release(); d_cur.release();
+    d_off.release(); d_len.release(); d_cnt.release(); d_fs.release();
     // Counter insertion order under -j1 = ascending first-seen unit (mapper.py:88)
     std::vector<int64_t> order(C);
     std::iota(order.begin(), order.end(), 0);
@@ -673,7 +726,12 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
     HIP_TRY(hipMemcpy(m->counters.p, cur.data(), CTR_WORDS * 8, hipMemcpyHostToDevice));
     if (n_classes) {
         const int64_t M = class_offsets[n_classes];
-        SKM_TRY(table_reserve(m, n_classes));
+        {   // foreign classes may all be new: size for them at load <= 0.5, unbounded probes
+            uint64_t want = 1 << 16;
+            while ((double)want * 0.5 < (double)(m->host_classes + n_classes + 1024)) want <<= 1;
+            SKM_TRY(table_grow(m, want, 0));
+            SKM_TRY(m->class_list.ensure((size_t)(m->host_classes + n_classes + 1024), true, m->stream));
+        }
         SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + M + 1024), true, m->stream));
         bind_table(m, m->t.slot_mask + 1);
         DBuf<int64_t> d_off, d_cnt, d_fs; DBuf<int32_t> d_ids;
@@ -685,7 +743,7 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
         if (M) HIP_TRY(hipMemcpy(d_ids.p, class_targets, M * 4, hipMemcpyHostToDevice));
         launch_class_merge(m->t, n_classes, d_off.p, d_ids.p, d_cnt.p, d_fs.p, m->stream);
         HIP_TRY(hipGetLastError());
-        unsigned long long ctr[4];
+        unsigned long long ctr[8];
         HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
         int rc = read_error(m);
         d_off.release(); d_cnt.release(); d_fs.release(); d_ids.release();
@@ -736,11 +794,11 @@ extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
 // access counters of the STATS build of the map kernel (SKM_MAP_STATS=1):
 // [0]=reads [1]=read bases [2]=lookups [3]=slots [4]=contig reads [5]=targets
 // copied [6]=targets merged [7]=8-base fetches [8]=merges [9]=tuple ids
-extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[16])
+extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[32])
 {
     if (!m || !out) return fail(SKM_ERR_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(m->mu);
-    for (int i = 0; i < 16; ++i) out[i] = (int64_t)m->stats_total[i];
+    for (int i = 0; i < 32; ++i) out[i] = (int64_t)m->stats_total[i];
     return SKM_OK;
 }
 
@@ -782,7 +840,7 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     q->n_tx = n_tx;
     q->n_classes = n_classes;
     q->n_ids = n_ids;
-    HIP_TRY(hipStreamCreate(&q->stream));
+    HIP_TRY(pool_stream_acquire(&q->stream));
     for (auto &e : q->ev) HIP_TRY(hipEventCreate(&e));
     const size_t C = (size_t)std::max<int64_t>(n_classes, 1), M = (size_t)std::max<int64_t>(n_ids, 1);
     const size_t T = (size_t)std::max<int64_t>(n_tx, 1);
@@ -1028,7 +1086,7 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
     q->cum.release(); q->draw.release();
     for (auto &e : q->ev) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(q->stream);
+    pool_stream_release(q->stream);
     delete q;
     return SKM_OK;
 }

@@ -36,13 +36,16 @@ class_init_kernel(ClassSlot *slots, int32_t *arena_len, uint64_t n_slots)
     }
 }
 
-// find-or-claim the slot whose tag is `key`; returns the slot index
+// find-or-claim the slot whose tag is `key`; returns the slot index, or ~0
+// when `limit` probes did not reach the key or a free slot (table too full:
+// the host grows it and retries the deferred units)
 __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned long long key,
-                                                bool &claimed)
+                                                bool &claimed, uint64_t limit)
 {
     uint64_t slot = key & t.slot_mask;
     claimed = false;
-    for (uint64_t n = 0; n <= t.slot_mask; ++n) {
+    if (limit > t.slot_mask + 1) limit = t.slot_mask + 1;
+    for (uint64_t n = 0; n < limit; ++n) {
         unsigned long long cur = __hip_atomic_load(&t.slots[slot].key, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0) {
@@ -52,14 +55,15 @@ __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned lo
         if (cur == key) return slot;
         slot = (slot + 1) & t.slot_mask;
     }
-    return ~0ULL;    // table full (the host grows it long before)
+    return ~0ULL;
 }
 
 __global__ void __launch_bounds__(256)
-class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot)
+class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot, bool retry_deferred)
 {
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
+        if (retry_deferred && unit_slot[u] != -2) continue;
         const unsigned long long key = b.unit_key[u];
         if (key == 0) {                       // empty tuple = unaligned, mapper.py:87
             atomicAdd(t.n_unaligned, 1ULL);
@@ -67,14 +71,19 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
             continue;
         }
         bool claimed;
-        const uint64_t slot = probe_claim(t, key, claimed);
-        if (slot == ~0ULL) { atomicExch(t.error, SKM_ERR_STATE); unit_slot[u] = -1; continue; }
+        const uint64_t slot = probe_claim(t, key, claimed, CLASS_PROBE_LIMIT);
+        if (slot == ~0ULL) {                  // deferred: counted after the table has grown
+            atomicAdd(t.n_deferred, 1ULL);
+            unit_slot[u] = -2;
+            continue;
+        }
         if (claimed) atomicAdd(t.n_classes, 1ULL);
         atomicAdd(&t.slots[slot].count, 1ULL);
         atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
         unit_slot[u] = (int64_t)slot;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(t.n_units, (unsigned long long)b.n_units);
+    if (!retry_deferred && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(t.n_units, (unsigned long long)b.n_units);
 }
 
 __global__ void __launch_bounds__(256)
@@ -108,19 +117,51 @@ class_verify_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *
 __global__ void __launch_bounds__(256)
 class_commit_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *unit_slot)
 {
-    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
-         u += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t slot = unit_slot[u];
-        if (slot < 0) continue;
-        if (t.slots[slot].arena_offset >= 0) continue;
-        if ((int64_t)t.slots[slot].first_seen - unit_base != u) continue;
-        const int n = b.unit_count[u];
-        const long long off = (long long)atomicAdd(t.arena_cursor, (unsigned long long)n);
-        if (off + n > t.arena_capacity) { atomicExch(t.error, SKM_ERR_STATE); continue; }
-        const int32_t *mine = b.unit_entries + b.unit_offset[u];
-        for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(mine[i]);
-        t.arena_len[slot] = n;
-        t.slots[slot].arena_offset = off;
+    const int lane = threadIdx.x & 63;
+    const int64_t total = (int64_t)gridDim.x * blockDim.x;
+    // whole waves iterate together: one arena / registry allocation per wave
+    for (int64_t first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x - lane; first < b.n_units;
+         first += total) {
+        const int64_t u = first + lane;
+        int64_t slot = -1;
+        int n = 0;
+        if (u < b.n_units) {
+            slot = unit_slot[u];
+            if (slot >= 0 && (t.slots[slot].arena_offset >= 0
+                              || (int64_t)t.slots[slot].first_seen - unit_base != u))
+                slot = -1;                    // not the representative of a new class
+            if (slot >= 0) n = b.unit_count[u];
+        }
+        const unsigned long long mine = __ballot(slot >= 0);
+        if (mine == 0) continue;
+        int scan = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(scan, d, 64);
+            if (lane >= d) scan += up;
+        }
+        const int wave_ids = __shfl(scan, 63, 64);
+        const int wave_classes = __popcll(mine);
+        unsigned long long arena_base = 0, list_base = 0;
+        if (lane == 0) {
+            arena_base = atomicAdd(t.arena_cursor, (unsigned long long)wave_ids);
+            list_base = atomicAdd(t.n_listed, (unsigned long long)wave_classes);
+        }
+        arena_base = __shfl(arena_base, 0, 64);
+        list_base = __shfl(list_base, 0, 64);
+        if (slot >= 0) {
+            const long long off = (long long)arena_base + scan - n;
+            const long long k = (long long)list_base + __popcll(mine & ((1ULL << lane) - 1));
+            if (off + n > t.arena_capacity || k >= t.class_list_capacity) {
+                atomicExch(t.error, SKM_ERR_STATE);
+                continue;
+            }
+            const int32_t *entries = b.unit_entries + b.unit_offset[u];
+            for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(entries[i]);
+            t.arena_len[slot] = n;
+            t.slots[slot].arena_offset = off;
+            t.class_list[k] = slot;
+        }
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_FRAGMENT_LENGTH;
          i += gridDim.x * blockDim.x) {
@@ -128,34 +169,45 @@ class_commit_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *
     }
 }
 
-// move every class of `from` into the (larger, initialised) table `to`
+// move every occupied slot of `from` into the (larger, initialised) table `to`
+// and record where it went, so that the registry and the unit -> slot map of a
+// batch in flight can be redirected
 __global__ void __launch_bounds__(256)
-class_rehash_kernel(ClassTable from, ClassTable to)
+class_rehash_kernel(ClassTable from, ClassTable to, int64_t *forward)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= from.slot_mask;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const ClassSlot s = from.slots[i];
-        if (s.key == 0) continue;
+        if (s.key == 0) { forward[i] = -1; continue; }
         bool claimed;
-        const uint64_t slot = probe_claim(to, s.key, claimed);
-        if (slot == ~0ULL || !claimed) { atomicExch(to.error, SKM_ERR_STATE); continue; }
+        const uint64_t slot = probe_claim(to, s.key, claimed, ~0ULL);
+        if (slot == ~0ULL || !claimed) { atomicExch(to.error, SKM_ERR_STATE); forward[i] = -1; continue; }
         to.slots[slot].count = s.count;
         to.slots[slot].first_seen = s.first_seen;
         to.slots[slot].arena_offset = s.arena_offset;
         to.arena_len[slot] = from.arena_len[i];
+        forward[i] = (int64_t)slot;
     }
 }
 
-// dense list of classes for the EM: arena offset, tuple length, count as f8
 __global__ void __launch_bounds__(256)
-class_compact_kernel(ClassTable t, int64_t *cls_offset, int32_t *cls_len, double *cls_count,
-                     unsigned long long *cls_first_seen, unsigned long long *cursor)
+slot_remap_kernel(int64_t *slots, int64_t n, const int64_t *forward)
 {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= t.slot_mask;
-         i += (uint64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x)
+        if (slots[k] >= 0) slots[k] = forward[slots[k]];
+}
+
+// dense dump of the classes (registry order): arena offset, tuple length,
+// count as f8, first-seen unit
+__global__ void __launch_bounds__(256)
+class_compact_kernel(ClassTable t, int64_t n_classes, int64_t *cls_offset, int64_t *cls_len,
+                     double *cls_count, unsigned long long *cls_first_seen)
+{
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_classes;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t.class_list[k];
         const ClassSlot s = t.slots[i];
-        if (s.key == 0) continue;
-        const unsigned long long k = atomicAdd(cursor, 1ULL);
         cls_offset[k] = s.arena_offset;
         cls_len[k] = t.arena_len[i];
         cls_count[k] = (double)s.count;
@@ -181,14 +233,19 @@ class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets
         }
         if (key == 0) key = 1;
         bool claimed;
-        const uint64_t slot = probe_claim(t, key, claimed);
+        const uint64_t slot = probe_claim(t, key, claimed, ~0ULL);
         if (slot == ~0ULL) { atomicExch(t.error, SKM_ERR_STATE); continue; }
         if (claimed) {
             const long long a = (long long)atomicAdd(t.arena_cursor, (unsigned long long)n);
-            if (a + n > t.arena_capacity) { atomicExch(t.error, SKM_ERR_STATE); continue; }
+            const long long k = (long long)atomicAdd(t.n_listed, 1ULL);
+            if (a + n > t.arena_capacity || k >= t.class_list_capacity) {
+                atomicExch(t.error, SKM_ERR_STATE);
+                continue;
+            }
             for (int i = 0; i < n; ++i) t.arena[a + i] = class_targets[off + i];
             t.arena_len[slot] = n;
             t.slots[slot].arena_offset = a;
+            t.class_list[k] = (int64_t)slot;
             atomicAdd(t.n_classes, 1ULL);
         } else {
             // classes of the resident table are all committed between batches
@@ -217,11 +274,11 @@ void launch_class_init(const ClassTable &t, hipStream_t stream)
 }
 
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                         int64_t *unit_slot, hipStream_t stream)
+                         int64_t *unit_slot, bool retry_deferred, hipStream_t stream)
 {
     if (b.n_units == 0) return;
     hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
-                       unit_base, unit_slot);
+                       unit_base, unit_slot, retry_deferred);
 }
 
 void launch_class_verify_commit(const ClassTable &t, const MapBatch &b, int64_t unit_base,
@@ -234,18 +291,26 @@ void launch_class_verify_commit(const ClassTable &t, const MapBatch &b, int64_t 
                        unit_base, unit_slot);
 }
 
-void launch_class_rehash(const ClassTable &from, const ClassTable &to, hipStream_t stream)
+void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,
+                         hipStream_t stream)
 {
-    hipLaunchKernelGGL(class_rehash_kernel, dim3(grid_for((int64_t)from.slot_mask + 1)), dim3(256),
-                       0, stream, from, to);
+    hipLaunchKernelGGL(class_rehash_kernel, dim3(grid_for((int64_t)from.slot_mask + 1)), dim3(256), 0,
+                       stream, from, to, forward);
 }
 
-void launch_class_compact(const ClassTable &t, int64_t *cls_offset, int32_t *cls_len,
-                          double *cls_count, unsigned long long *cls_first_seen,
-                          unsigned long long *cursor, hipStream_t stream)
+void launch_slot_remap(int64_t *slots, int64_t n, const int64_t *forward, hipStream_t stream)
 {
-    hipLaunchKernelGGL(class_compact_kernel, dim3(grid_for((int64_t)t.slot_mask + 1)), dim3(256), 0,
-                       stream, t, cls_offset, cls_len, cls_count, cls_first_seen, cursor);
+    if (n == 0) return;
+    hipLaunchKernelGGL(slot_remap_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slots, n, forward);
+}
+
+void launch_class_compact(const ClassTable &t, int64_t n_classes, int64_t *cls_offset,
+                          int64_t *cls_len, double *cls_count, unsigned long long *cls_first_seen,
+                          hipStream_t stream)
+{
+    if (n_classes == 0) return;
+    hipLaunchKernelGGL(class_compact_kernel, dim3(grid_for(n_classes)), dim3(256), 0, stream, t,
+                       n_classes, cls_offset, cls_len, cls_count, cls_first_seen);
 }
 
 void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *class_offsets,

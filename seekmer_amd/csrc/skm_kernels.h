@@ -25,6 +25,7 @@ struct MapBatch {
     unsigned long long *ids_cursor;
     unsigned long long *fld;      // [2000] batch-local histogram
     unsigned long long *stats;    // [16] access counters (STATS build only)
+    int32_t vote[8];              // quorum per action: lookup, copy, merge, align, emit
 };
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
@@ -52,17 +53,24 @@ struct ClassTable {
     unsigned long long *n_unaligned;
     unsigned long long *n_units;
     unsigned long long *global_fld;   // [2000]
+    int64_t *class_list;          // dense registry: slot of every committed class
+    int64_t class_list_capacity;
+    unsigned long long *n_listed;
+    unsigned long long *n_deferred;   // units whose probe ran past PROBE_LIMIT (table too full)
     int *error;                   // SKM_ERR_* raised by a kernel
 };
+constexpr int CLASS_PROBE_LIMIT = 128;
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                         int64_t *unit_slot, hipStream_t stream);
+                         int64_t *unit_slot, bool retry_deferred, hipStream_t stream);
 void launch_class_verify_commit(const ClassTable &t, const MapBatch &b, int64_t unit_base,
                                 const int64_t *unit_slot, hipStream_t stream);
-void launch_class_rehash(const ClassTable &from, const ClassTable &to, hipStream_t stream);
+void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,
+                         hipStream_t stream);
+void launch_slot_remap(int64_t *slots, int64_t n, const int64_t *forward, hipStream_t stream);
 void launch_class_init(const ClassTable &t, hipStream_t stream);
-void launch_class_compact(const ClassTable &t, int64_t *cls_offset, int32_t *cls_len,
-                          double *cls_count, unsigned long long *cls_first_seen,
-                          unsigned long long *cursor, hipStream_t stream);
+void launch_class_compact(const ClassTable &t, int64_t n_classes, int64_t *cls_offset,
+                          int64_t *cls_len, double *cls_count, unsigned long long *cls_first_seen,
+                          hipStream_t stream);
 void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *class_offsets,
                         const int32_t *class_targets, const int64_t *class_counts,
                         const int64_t *first_seen, hipStream_t stream);

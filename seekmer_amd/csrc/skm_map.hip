@@ -16,14 +16,33 @@
 namespace skm {
 
 // ---------------------------------------------------------------- pack_reads
-// One lane per 32-base word of a read.  ASCII -> (2-bit code word, 32-bit
-// ACGT mask word).  Word index space is [n_reads][words_per_read].
+// One lane per 32-base word of a read: ASCII -> (2-bit code word, 32-bit ACGT
+// mask word).  The 32 bases come in as two (unaligned) 16-byte loads, so a
+// wave reads 2 KiB of consecutive FASTQ bases per instruction pair.  Word
+// index space is [n_reads][words_per_read].
+struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };
+
+__device__ __forceinline__ void pack_dword(uint32_t w, int first, int n, uint64_t &codes, uint32_t &acgt)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = first + k;
+        if (i < n) {
+            const uint32_t ch = (w >> (8 * k)) & 0xffu;
+            codes |= (uint64_t)two_bit_encode(ch) << (62 - 2 * i);
+            const bool up = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+            acgt |= (uint32_t)up << (31 - i);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offsets,
                   int64_t n_reads, int words_per_read,
                   uint64_t *__restrict__ codes, uint32_t *__restrict__ acgt)
 {
     const int64_t total = n_reads * (int64_t)words_per_read;
+    const int64_t end_of_bases = offsets[n_reads];
     for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = g / words_per_read;
@@ -35,12 +54,16 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
         const int first = w * 32;
         if (first < len) {
             const int n = min(32, len - first);
-            const uint8_t *p = bases + begin + first;
-            for (int i = 0; i < n; ++i) {
-                const uint32_t ch = p[i];
-                c |= (uint64_t)two_bit_encode(ch) << (62 - 2 * i);
-                const bool up = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-                m |= (uint32_t)up << (31 - i);
+            const int64_t at = begin + first;
+            if (at + 32 <= end_of_bases) {
+                const Bytes16 lo = *reinterpret_cast<const Bytes16 *>(bases + at);
+                const Bytes16 hi = *reinterpret_cast<const Bytes16 *>(bases + at + 16);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pack_dword(lo.w[d], 4 * d, n, c, m);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pack_dword(hi.w[d], 16 + 4 * d, n, c, m);
+            } else {                                   // last bytes of the batch: stay in bounds
+                for (int i = 0; i < n; ++i) pack_dword(bases[at + i], i, i + 1, c, m);
             }
         }
         codes[g] = c;
@@ -252,8 +275,19 @@ __device__ __forceinline__ uint64_t tuple_key_step(uint64_t h, uint32_t id)
 // States that run without a lookup:
 //   N_LEFT (:229-246, :270-275)  N_RIGHT_ENTER (:174-176)  N_RIGHT (:285-308, :335-343)
 //   N_AFTER (:177-193)  N_MATE_DONE  UNIT_DONE (map_read_pair :129-144 + batch loop :89-94)
-enum : int { ST_IDLE = 0, Y_FIRST, Y_LJ, Y_LS, Y_RA, Y_RJ, N_LEFT, N_RIGHT_ENTER, N_RIGHT, N_AFTER,
-             N_MATE_DONE, ST_UNIT_DONE };
+// Scheduling.  With 64 lanes spread over half a dozen heavy actions, running
+// every action every round keeps each at ~15 % lane utilisation (measured:
+// the kernel is VALU-issue bound, not memory bound).  So lanes WAIT in their
+// state and an action is executed only when enough lanes want it (or when it
+// is the most wanted and nothing else ran): convergence is restored by
+// voting, the price being a longer per-unit latency that the refill hides.
+enum : int { ST_IDLE = 0,
+             Y_FIRST, Y_LJ, Y_LS, Y_RA, Y_RJ,          // want a lookup
+             C_COPY,                                   // want map_contig
+             M_LJ, M_LS, M_RJ,                         // want a list merge
+             N_LEFT, N_RIGHT,                          // want an 8-base alignment step
+             N_RIGHT_ENTER, N_AFTER, N_MATE_DONE,      // cheap transitions, run every round
+             ST_UNIT_DONE };                           // want emission
 
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
 
@@ -273,6 +307,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
     int32_t *const ws2 = ws1 + (size_t)ix.max_target_count * stride;
     LaneStats ls = {0, 0, 0, 0, 0, 0, 0};
     uint64_t read_bases = 0, n_reads = 0, tuple_ids = 0;
+    // scheduler census (STATS build): [0]=rounds, then executions / lanes per action
+    uint32_t census[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // this wave's private range of units: no atomics for work distribution
     const int64_t n_waves = total_threads >> 6;
@@ -280,6 +316,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
     int64_t next = (gtid >> 6) * per_wave;
     const int64_t limit = min(b.n_units, next + per_wave);
     int64_t chunk_pos = 0, chunk_end = 0;      // wave-uniform slice of the entry arena
+    const int th_lookup = b.vote[0], th_copy = b.vote[1], th_merge = b.vote[2],
+              th_align = b.vote[3], th_emit = b.vote[4];
 
     // per-lane machine state
     int state = ST_IDLE;
@@ -317,119 +355,14 @@ map_units_kernel(DevIndex ix, MapBatch b)
         }
         if (__ballot(state != ST_IDLE) == 0) break;
 
-        const TList list{mate ? ws2 : ws1, stride};
-
-        // ------------------------------------------ the one index lookup site
-        Coord pos = invalid_coord();
-        if (state >= Y_FIRST && state <= Y_RJ) pos = map_kmer<STATS>(ix, kmer, &ls);
-
-        // _find_first_kmer, _mapper.pyx:199-216
-        if (state == Y_FIRST) {
-            span.anchor = pos;
-            if (pos.offset >= 0) {
-                span.begin = scan_i - K;
-                span.end = span.begin;
-                map_contig<STATS>(ix, pos, list, span, &ls);
-                state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
-            } else if (scan_i < rv.len) {
-                kmer = ((kmer << 2) | read_code(rv, scan_i)) & KMER_MASK;     // _kmer.append
-                ++scan_i;
-            } else {
-                state = N_MATE_DONE;                  // no hit: returned as is, no retry (:170-171, :186-187)
-            }
-        } else if (state == Y_RA) {
-            span.anchor = pos;
-            state = N_RIGHT;
-        } else if (state == Y_LJ || state == Y_LS || state == Y_RJ) {
-            // the one merge site: `anchor = map_kmer(...)`, then _filter_on_contig
-            span.anchor = pos;
-            const bool ok = pos.offset >= 0 && filter_on_contig<STATS>(ix, list, span, &ls);
-            if (state == Y_LJ) {
-                if (ok) state = N_LEFT;
-                else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }      // :252-256
-                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; } // :257-259
-            } else if (state == Y_LS) {
-                if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }             // :260-263
-            } else {
-                if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }            // :312-315
-            }
-        }
-
-        // ------------------------------------------ run until the next lookup
-        while (__ballot(state >= N_LEFT && state <= N_MATE_DONE) != 0) {
-            if (state == N_LEFT) {
-                // _filter_targets_to_left loop head + body up to the junction k-mer,
-                // or the closing 8-base check once the read no longer passes the edge
-                const bool forward = span.anchor.entry >= 0;
-                const int move = left_move(ix, span.anchor);
-                if (STATS) ls.contig_reads++;
-                const bool in_loop = span.begin > move;
-                int at;
-                if (in_loop) {
-                    span.begin -= move;
-                    span.anchor.offset -= forward ? move : -move;
-                    at = span.begin;
-                } else {
-                    span.anchor.offset -= forward ? span.begin : -span.begin;
-                    at = 0;
-                }
-                const int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
-                if (!in_loop) {
-                    if (shift == INVALID_SHIFT) span.n = 0;
-                    state = N_RIGHT_ENTER;
-                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
-                    span.n = 0;
-                    state = N_AFTER;
-                } else {
-                    span.begin -= shift + 1;
-                    if (span.begin < 0) {
-                        span.begin = 0;
-                        state = N_RIGHT_ENTER;
-                    } else {
-                        kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)      // _kmer.prepend
-                               | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
-                        state = Y_LJ;
-                    }
-                }
-            } else if (state == N_RIGHT_ENTER) {
+        // ------------------------------------------------ cheap transitions
+        while (__ballot(state >= N_RIGHT_ENTER && state <= N_MATE_DONE) != 0) {
+            if (state == N_RIGHT_ENTER) {                 // map_read, :174-176 / :190-192
                 if (span.n != 0 && span.end < rv.len - K) {
                     kmer = read_kmer(rv, span.end);
                     state = Y_RA;
                 } else {
                     state = N_AFTER;
-                }
-            } else if (state == N_RIGHT) {
-                const bool forward = span.anchor.entry >= 0;
-                const int move = right_move(ix, span.anchor);
-                if (STATS) ls.contig_reads++;
-                const int rest = rv.len - span.end - K;
-                const bool in_loop = rest > move;
-                int at;
-                if (in_loop) {
-                    span.end += move;
-                    span.anchor.offset += forward ? move : -move;
-                    at = span.end + K - ALIGN_LENGTH;
-                } else {
-                    span.anchor.offset += forward ? rest : -rest;
-                    at = rv.len - ALIGN_LENGTH;
-                }
-                const int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
-                if (!in_loop) {
-                    if (shift == INVALID_SHIFT) span.n = 0;
-                    state = N_AFTER;
-                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
-                    span.n = 0;
-                    state = N_AFTER;
-                } else {
-                    span.end += shift + 1;
-                    if (span.end + K > rv.len) {
-                        span.end = rv.len - K;
-                        state = N_AFTER;
-                    } else {
-                        kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)      // _kmer.append
-                                | read_code(rv, span.end + K - 1)) & KMER_MASK;
-                        state = Y_RJ;
-                    }
                 }
             } else if (state == N_AFTER) {
                 if (span.n != 0 || attempt == 1) {
@@ -467,9 +400,160 @@ map_units_kernel(DevIndex ix, MapBatch b)
             }
         }
 
+        // --------------------------------------------------------- the vote
+        const int n_lookup = __popcll(__ballot(state >= Y_FIRST && state <= Y_RJ));
+        const int n_copy = __popcll(__ballot(state == C_COPY));
+        const int n_merge = __popcll(__ballot(state >= M_LJ && state <= M_RJ));
+        const int n_left = __popcll(__ballot(state == N_LEFT));
+        const int n_right = __popcll(__ballot(state == N_RIGHT));
+        const int n_emit = __popcll(__ballot(state == ST_UNIT_DONE));
+        bool do_lookup = n_lookup >= th_lookup, do_copy = n_copy >= th_copy,
+             do_merge = n_merge >= th_merge, do_left = n_left >= th_align,
+             do_right = n_right >= th_align, do_emit = n_emit >= th_emit;
+        if (!(do_lookup || do_copy || do_merge || do_left || do_right || do_emit)) {
+            // nothing reached its quorum: run the most wanted action
+            const int best = max(max(max(n_lookup, n_copy), max(n_merge, n_left)), max(n_right, n_emit));
+            if (n_lookup == best) do_lookup = true;
+            else if (n_merge == best) do_merge = true;
+            else if (n_left == best) do_left = true;
+            else if (n_right == best) do_right = true;
+            else if (n_copy == best) do_copy = true;
+            else do_emit = true;
+        }
+
+        if (STATS) {
+            census[0]++;
+            if (do_lookup) { census[1]++; census[2] += n_lookup; }
+            if (do_copy) { census[3]++; census[4] += n_copy; }
+            if (do_merge) { census[5]++; census[6] += n_merge; }
+            if (do_left) { census[7]++; census[8] += n_left; }
+            if (do_right) { census[9]++; census[10] += n_right; }
+            if (do_emit) { census[11]++; census[12] += n_emit; }
+        }
+
+        const TList list{mate ? ws2 : ws1, stride};
+
+        // ------------------------------------------ the one index lookup site
+        if (do_lookup && state >= Y_FIRST && state <= Y_RJ) {
+            const Coord pos = map_kmer<STATS>(ix, kmer, &ls);
+            span.anchor = pos;
+            if (state == Y_FIRST) {                       // _find_first_kmer, :199-216
+                if (pos.offset >= 0) {
+                    span.begin = scan_i - K;
+                    span.end = span.begin;
+                    state = C_COPY;
+                } else if (scan_i < rv.len) {
+                    kmer = ((kmer << 2) | read_code(rv, scan_i)) & KMER_MASK;     // _kmer.append
+                    ++scan_i;
+                } else {
+                    state = N_MATE_DONE;                  // no hit: returned as is, no retry
+                }
+            } else if (state == Y_RA) {
+                state = N_RIGHT;
+            } else if (pos.offset >= 0) {
+                state = state == Y_LJ ? M_LJ : (state == Y_LS ? M_LS : M_RJ);
+            } else if (state == Y_LJ) {                   // miss at the junction, :250-259
+                if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
+            } else {                                      // Y_LS :260-263, Y_RJ :312-315
+                span.n = 0;
+                state = N_AFTER;
+            }
+        }
+
+        // ---------------------------------------------- KMerIndex.map_contig
+        if (do_copy && state == C_COPY) {
+            map_contig<STATS>(ix, span.anchor, list, span, &ls);
+            state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+        }
+
+        // ------------------------------------- the one _filter_on_contig site
+        if (do_merge && state >= M_LJ && state <= M_RJ) {
+            const bool ok = filter_on_contig<STATS>(ix, list, span, &ls);
+            if (state == M_LJ) {
+                if (ok) state = N_LEFT;
+                else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
+            } else if (state == M_LS) {
+                if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
+            } else {
+                if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
+            }
+        }
+
+        // ------------------- _filter_targets_to_left: loop head + alignment step
+        if (do_left && state == N_LEFT) {
+            const bool forward = span.anchor.entry >= 0;
+            const int move = left_move(ix, span.anchor);
+            if (STATS) ls.contig_reads++;
+            const bool in_loop = span.begin > move;
+            int at;
+            if (in_loop) {
+                span.begin -= move;
+                span.anchor.offset -= forward ? move : -move;
+                at = span.begin;
+            } else {                                      // closing check, :270-275
+                span.anchor.offset -= forward ? span.begin : -span.begin;
+                at = 0;
+            }
+            const int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
+            if (!in_loop) {
+                if (shift == INVALID_SHIFT) span.n = 0;
+                state = N_RIGHT_ENTER;
+            } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                span.n = 0;
+                state = N_AFTER;
+            } else {
+                span.begin -= shift + 1;
+                if (span.begin < 0) {
+                    span.begin = 0;
+                    state = N_RIGHT_ENTER;
+                } else {
+                    kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)          // _kmer.prepend
+                           | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
+                    state = Y_LJ;
+                }
+            }
+        }
+
+        // ------------------ _filter_targets_to_right: loop head + alignment step
+        if (do_right && state == N_RIGHT) {
+            const bool forward = span.anchor.entry >= 0;
+            const int move = right_move(ix, span.anchor);
+            if (STATS) ls.contig_reads++;
+            const int rest = rv.len - span.end - K;
+            const bool in_loop = rest > move;
+            int at;
+            if (in_loop) {
+                span.end += move;
+                span.anchor.offset += forward ? move : -move;
+                at = span.end + K - ALIGN_LENGTH;
+            } else {                                      // closing check, :335-343
+                span.anchor.offset += forward ? rest : -rest;
+                at = rv.len - ALIGN_LENGTH;
+            }
+            const int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
+            if (!in_loop) {
+                if (shift == INVALID_SHIFT) span.n = 0;
+                state = N_AFTER;
+            } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                span.n = 0;
+                state = N_AFTER;
+            } else {
+                span.end += shift + 1;
+                if (span.end + K > rv.len) {
+                    span.end = rv.len - K;
+                    state = N_AFTER;
+                } else {
+                    kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)          // _kmer.append
+                            | read_code(rv, span.end + K - 1)) & KMER_MASK;
+                    state = Y_RJ;
+                }
+            }
+        }
+
         // --------------------------------------------------- finished units
-        const unsigned long long done = __ballot(state == ST_UNIT_DONE);
-        if (done == 0) continue;
+        if (!do_emit) continue;
         int n_out = 0;
         if (state == ST_UNIT_DONE) {
             if (b.paired) {
@@ -498,7 +582,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
             }
             n_out = span.n;
         }
-        // one slice of the entry arena for all lanes that finished this round
+        // one slice of the entry arena for all lanes that finish this round
         int scan = n_out;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -549,6 +633,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
         atomicAdd(&o[7], (unsigned long long)ls.seq_fetches);
         atomicAdd(&o[8], (unsigned long long)ls.merges);
         atomicAdd(&o[9], (unsigned long long)tuple_ids);
+        if (lane == 0)
+            for (int i = 0; i < 13; ++i) atomicAdd(&o[16 + i], (unsigned long long)census[i]);
     }
 }
 

@@ -5,6 +5,7 @@
 // sort and scan) do the ordering; the small kernels here only move indices.
 // One-time setup per quantification, not part of the per-step hot loop.
 #include "skm_kernels.h"
+#include "skm_pool.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -15,8 +16,8 @@ namespace {
 template <class T>
 struct Tmp {
     T *p = nullptr;
-    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
-    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return pool_alloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+    ~Tmp() { pool_free(p); }
 };
 
 #define QB_TRY(call) do { if ((call) != hipSuccess) return -1; } while (0)
@@ -28,16 +29,15 @@ iota_kernel(int32_t *out, int64_t n)
          i += (int64_t)gridDim.x * blockDim.x) out[i] = (int32_t)i;
 }
 
-// unordered dump of the table: arena offset, length, count, first-seen per class
+// dump of the table in registry order: arena offset, length, count, first-seen per class
 __global__ void __launch_bounds__(256)
-table_dump_kernel(ClassTable t, int64_t *arena_off, int64_t *len, double *count,
-                  unsigned long long *first_seen, unsigned long long *cursor)
+table_dump_kernel(ClassTable t, int64_t n_classes, int64_t *arena_off, int64_t *len, double *count,
+                  unsigned long long *first_seen)
 {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= t.slot_mask;
-         i += (uint64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_classes;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t.class_list[k];
         const ClassSlot s = t.slots[i];
-        if (s.key == 0) continue;
-        const unsigned long long k = atomicAdd(cursor, 1ULL);
         arena_off[k] = s.arena_offset;
         len[k] = t.arena_len[i];
         count[k] = (double)s.count;
@@ -166,14 +166,13 @@ int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids
     if (n_classes >= (1LL << 31) || n_ids >= (1LL << 31)) return -2;
     Tmp<int64_t> arena_off, len, len_sorted;
     Tmp<double> count;
-    Tmp<unsigned long long> first, first_sorted, cursor;
+    Tmp<unsigned long long> first, first_sorted;
     Tmp<int32_t> iota, perm;
     QB_TRY(arena_off.alloc(n_classes)); QB_TRY(len.alloc(n_classes)); QB_TRY(len_sorted.alloc(n_classes));
     QB_TRY(count.alloc(n_classes)); QB_TRY(first.alloc(n_classes)); QB_TRY(first_sorted.alloc(n_classes));
-    QB_TRY(cursor.alloc(1)); QB_TRY(iota.alloc(n_classes)); QB_TRY(perm.alloc(n_classes));
-    QB_TRY(hipMemsetAsync(cursor.p, 0, 8, stream));
-    hipLaunchKernelGGL(table_dump_kernel, dim3(blocks_for((int64_t)t.slot_mask + 1)), dim3(256), 0, stream,
-                       t, arena_off.p, len.p, count.p, first.p, cursor.p);
+    QB_TRY(iota.alloc(n_classes)); QB_TRY(perm.alloc(n_classes));
+    hipLaunchKernelGGL(table_dump_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream,
+                       t, n_classes, arena_off.p, len.p, count.p, first.p);
     hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, iota.p, n_classes);
     size_t bytes = 0;
     QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, first.p, first_sorted.p, iota.p, perm.p,

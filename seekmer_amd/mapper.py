@@ -229,11 +229,16 @@ class MapResult:
         _native.check(_native.hip().skm_mapper_set_stats(self._handle, int(bool(enable))))
 
     def access_stats(self):
-        out = (ctypes.c_int64 * 16)()
+        out = (ctypes.c_int64 * 32)()
         _native.check(_native.hip().skm_mapper_access_stats(self._handle, out))
         names = ('reads', 'read_bases', 'lookups', 'slots', 'contig_reads', 'targets_copied',
                  'targets_merged', 'seq_fetches', 'merges', 'tuple_ids')
-        return {n: int(out[i]) for i, n in enumerate(names)}
+        stats = {n: int(out[i]) for i, n in enumerate(names)}
+        census = ('rounds', 'lookup_exec', 'lookup_lanes', 'copy_exec', 'copy_lanes', 'merge_exec',
+                  'merge_lanes', 'left_exec', 'left_lanes', 'right_exec', 'right_lanes',
+                  'emit_exec', 'emit_lanes')
+        stats['census'] = {n: int(out[16 + i]) for i, n in enumerate(census)}
+        return stats
 
     def timing(self):
         out = (ctypes.c_double * 8)()
