@@ -114,6 +114,7 @@ struct skm_mapper {
     DBuf<int32_t> unit_begin, unit_end, unit_count;
     DBuf<Coord> unit_anchor;
     DBuf<int64_t> unit_offset, unit_slot;
+    DBuf<unsigned long long> unit_claim, claim_scan;
     DBuf<uint64_t> unit_key;
     DBuf<int32_t> unit_entries;
     DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
@@ -424,6 +425,8 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(m->unit_anchor.ensure(n_units));
     SKM_TRY(m->unit_offset.ensure(n_units));
     SKM_TRY(m->unit_slot.ensure(n_units));
+    SKM_TRY(m->unit_claim.ensure(n_units));
+    SKM_TRY(m->claim_scan.ensure(n_units));
     SKM_TRY(m->unit_key.ensure(n_units));
 
     SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
@@ -490,17 +493,32 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     bind_table(m, m->t.slot_mask + 1);
     for (int pass = 0;; ++pass) {
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
-        launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, pass > 0, m->stream);
+        launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, m->unit_claim.p, pass > 0, m->stream);
         HIP_TRY(hipGetLastError());
-        unsigned long long ctr[8];
-        HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
+        // registry index and arena offset of every class created in this pass
+        unsigned long long created = 0;
+        if (device_exclusive_scan_u64(m->unit_claim.p, m->claim_scan.p, n_units, &created, m->stream))
+            return fail(SKM_ERR_HIP, "prefix sum over the new classes failed: %s", hipGetErrorString(hipGetLastError()));
+        const int64_t new_classes = (int64_t)(created >> 40);
+        const int64_t new_ids = (int64_t)(created & ((1ULL << 40) - 1));
+        launch_class_commit(m->t, b, m->unit_slot.p, m->unit_claim.p, m->claim_scan.p, m->host_classes,
+                            m->host_arena_used, m->stream);
+        HIP_TRY(hipGetLastError());
+        m->host_classes += new_classes;
+        m->host_arena_used += new_ids;
+        unsigned long long totals[2] = {(unsigned long long)m->host_arena_used, (unsigned long long)m->host_classes};
+        HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_ARENA, &totals[0], 8, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_CLASSES, &totals[1], 8, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_LISTED, &totals[1], 8, hipMemcpyHostToDevice, m->stream));
+        unsigned long long deferred = 0;
+        HIP_TRY(hipMemcpyAsync(&deferred, m->counters.p + CTR_DEFERRED, 8, hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
-        if (ctr[CTR_DEFERRED] == 0) break;
+        if (deferred == 0) break;
         if (pass > 40) return fail(SKM_ERR_STATE, "class table cannot absorb the batch");
-        // too full for bounded probing: grow 4x (classes claimed so far move along), retry the rest
+        // too full for bounded probing: grow 4x (its classes move along), retry the deferred units
         SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 4, n_units));
     }
-    launch_class_verify_commit(m->t, b, m->units_done, m->unit_slot.p, m->stream);
+    launch_class_verify(m->t, b, m->unit_slot.p, m->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev[3], m->stream));
     unsigned long long ctr[8];
@@ -553,7 +571,7 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->error.release(); m->bases.release(); m->offsets.release(); m->codes.release();
     m->acgt.release(); m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
     m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
-    m->unit_slot.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
+    m->unit_slot.release(); m->unit_claim.release(); m->claim_scan.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
     pool_stream_release(m->stream);
     delete m;

@@ -4,18 +4,20 @@
 // in MapResult.summarize (mapper.py:85-92).
 //
 // Open-addressing table keyed by a 64-bit tag of the tuple.  A batch is
-// counted in three launches so that no lane ever spins on another lane:
+// counted in launches, so that no lane ever spins on another lane:
 //   insert  -- claim or find the slot by tag (atomicCAS), count++ and
-//              first_seen = min(global unit index)            (integer atomics)
-//   verify  -- every unit compares its FULL tuple with the class
-//              representative (the committed arena copy, or, for a class born
-//              in this batch, the unit that holds first_seen); a mismatch is a
-//              64-bit tag collision and raises SKM_ERR_COLLISION, so counts are
-//              exact or the call fails -- never silently merged
-//   commit  -- the representative of each new class copies its tuple into the
-//              arena
-// Launch boundaries provide all inter-workgroup ordering; within a launch only
-// device-scope atomics touch shared words.
+//              first_seen = min(global unit index) (integer atomics); the lane
+//              whose CAS created the class is its creator
+//   (scan)  -- device-wide exclusive prefix sum over the creators gives each new
+//              class its registry index and arena offset: no allocation atomics
+//   commit  -- creators store their tuple in the arena and the slot in the
+//              dense class registry
+//   verify  -- every unit compares its FULL tuple with the stored one; a
+//              mismatch is a 64-bit tag collision and raises
+//              SKM_ERR_COLLISION, so counts are exact or the call fails --
+//              never silently merged
+// The launch boundary orders the tuple stores before the compares; within a
+// launch only device-scope atomics touch shared words.
 #include "skm_kernels.h"
 #include "../../include/seekmer_hip.h"
 
@@ -59,10 +61,12 @@ __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned lo
 }
 
 __global__ void __launch_bounds__(256)
-class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot, bool retry_deferred)
+class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot,
+                    unsigned long long *unit_claim, bool retry_deferred)
 {
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
+        unit_claim[u] = 0;
         if (retry_deferred && unit_slot[u] != -2) continue;
         const unsigned long long key = b.unit_key[u];
         if (key == 0) {                       // empty tuple = unaligned, mapper.py:87
@@ -77,91 +81,58 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
             unit_slot[u] = -2;
             continue;
         }
-        if (claimed) atomicAdd(t.n_classes, 1ULL);
         atomicAdd(&t.slots[slot].count, 1ULL);
         atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
         unit_slot[u] = (int64_t)slot;
+        // the creator of a class stores its tuple later (class_commit_kernel): one class
+        // (bits 40+) and n arena ids (bits 0-39), placed by a device-wide prefix sum
+        if (claimed) unit_claim[u] = (1ULL << 40) | (unsigned long long)b.unit_count[u];
     }
     if (!retry_deferred && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(t.n_units, (unsigned long long)b.n_units);
 }
 
+// creators copy their tuple to the arena position the prefix sum assigned
 __global__ void __launch_bounds__(256)
-class_verify_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *unit_slot)
+class_commit_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot,
+                    const unsigned long long *unit_claim, const unsigned long long *claim_scan,
+                    int64_t class_base, int64_t arena_base)
+{
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        if (unit_claim[u] == 0) continue;
+        const int n = (int)(unit_claim[u] & ((1ULL << 40) - 1));
+        const long long k = class_base + (long long)(claim_scan[u] >> 40);
+        const long long off = arena_base + (long long)(claim_scan[u] & ((1ULL << 40) - 1));
+        if (off + n > t.arena_capacity || k >= t.class_list_capacity) {
+            atomicExch(t.error, SKM_ERR_STATE);
+            continue;
+        }
+        const int64_t slot = unit_slot[u];
+        const int32_t *entries = b.unit_entries + b.unit_offset[u];
+        for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(entries[i]);
+        t.arena_len[slot] = n;
+        t.slots[slot].arena_offset = off;
+        t.class_list[k] = slot;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+class_verify_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot)
 {
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = unit_slot[u];
         if (slot < 0) continue;
         const int n = b.unit_count[u];
-        const int32_t *mine = b.unit_entries + b.unit_offset[u];
-        const long long committed = t.slots[slot].arena_offset;
-        bool same = true;
-        if (committed >= 0) {
-            same = t.arena_len[slot] == n;
-            const int32_t *ref = t.arena + committed;
+        const long long stored = t.slots[slot].arena_offset;
+        bool same = stored >= 0 && t.arena_len[slot] == n;
+        if (same) {
+            const int32_t *mine = b.unit_entries + b.unit_offset[u];
+            const int32_t *ref = t.arena + stored;
             for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
-        } else {
-            const int64_t rep = (int64_t)t.slots[slot].first_seen - unit_base;
-            if (rep < 0 || rep >= b.n_units) { atomicExch(t.error, SKM_ERR_STATE); continue; }
-            if (rep != u) {
-                same = b.unit_count[rep] == n;
-                const int32_t *ref = b.unit_entries + b.unit_offset[rep];
-                for (int i = 0; same && i < n; ++i) same = unsigned_id(ref[i]) == unsigned_id(mine[i]);
-            }
         }
         if (!same) atomicExch(t.error, SKM_ERR_COLLISION);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-class_commit_kernel(ClassTable t, MapBatch b, int64_t unit_base, const int64_t *unit_slot)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t total = (int64_t)gridDim.x * blockDim.x;
-    // whole waves iterate together: one arena / registry allocation per wave
-    for (int64_t first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x - lane; first < b.n_units;
-         first += total) {
-        const int64_t u = first + lane;
-        int64_t slot = -1;
-        int n = 0;
-        if (u < b.n_units) {
-            slot = unit_slot[u];
-            if (slot >= 0 && (t.slots[slot].arena_offset >= 0
-                              || (int64_t)t.slots[slot].first_seen - unit_base != u))
-                slot = -1;                    // not the representative of a new class
-            if (slot >= 0) n = b.unit_count[u];
-        }
-        const unsigned long long mine = __ballot(slot >= 0);
-        if (mine == 0) continue;
-        int scan = n;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(scan, d, 64);
-            if (lane >= d) scan += up;
-        }
-        const int wave_ids = __shfl(scan, 63, 64);
-        const int wave_classes = __popcll(mine);
-        unsigned long long arena_base = 0, list_base = 0;
-        if (lane == 0) {
-            arena_base = atomicAdd(t.arena_cursor, (unsigned long long)wave_ids);
-            list_base = atomicAdd(t.n_listed, (unsigned long long)wave_classes);
-        }
-        arena_base = __shfl(arena_base, 0, 64);
-        list_base = __shfl(list_base, 0, 64);
-        if (slot >= 0) {
-            const long long off = (long long)arena_base + scan - n;
-            const long long k = (long long)list_base + __popcll(mine & ((1ULL << lane) - 1));
-            if (off + n > t.arena_capacity || k >= t.class_list_capacity) {
-                atomicExch(t.error, SKM_ERR_STATE);
-                continue;
-            }
-            const int32_t *entries = b.unit_entries + b.unit_offset[u];
-            for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(entries[i]);
-            t.arena_len[slot] = n;
-            t.slots[slot].arena_offset = off;
-            t.class_list[k] = slot;
-        }
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_FRAGMENT_LENGTH;
          i += gridDim.x * blockDim.x) {
@@ -274,21 +245,29 @@ void launch_class_init(const ClassTable &t, hipStream_t stream)
 }
 
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                         int64_t *unit_slot, bool retry_deferred, hipStream_t stream)
+                         int64_t *unit_slot, unsigned long long *unit_claim, bool retry_deferred,
+                         hipStream_t stream)
 {
     if (b.n_units == 0) return;
     hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
-                       unit_base, unit_slot, retry_deferred);
+                       unit_base, unit_slot, unit_claim, retry_deferred);
 }
 
-void launch_class_verify_commit(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                                const int64_t *unit_slot, hipStream_t stream)
+void launch_class_commit(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
+                         const unsigned long long *unit_claim, const unsigned long long *claim_scan,
+                         int64_t class_base, int64_t arena_base, hipStream_t stream)
+{
+    if (b.n_units == 0) return;
+    hipLaunchKernelGGL(class_commit_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
+                       unit_slot, unit_claim, claim_scan, class_base, arena_base);
+}
+
+void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
+                         hipStream_t stream)
 {
     if (b.n_units == 0) return;
     hipLaunchKernelGGL(class_verify_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
-                       unit_base, unit_slot);
-    hipLaunchKernelGGL(class_commit_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
-                       unit_base, unit_slot);
+                       unit_slot);
 }
 
 void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,

@@ -61,9 +61,16 @@ struct ClassTable {
 };
 constexpr int CLASS_PROBE_LIMIT = 128;
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                         int64_t *unit_slot, bool retry_deferred, hipStream_t stream);
-void launch_class_verify_commit(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                                const int64_t *unit_slot, hipStream_t stream);
+                         int64_t *unit_slot, unsigned long long *unit_claim, bool retry_deferred,
+                         hipStream_t stream);
+void launch_class_commit(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
+                         const unsigned long long *unit_claim, const unsigned long long *claim_scan,
+                         int64_t class_base, int64_t arena_base, hipStream_t stream);
+// exclusive prefix sum of n u64 values (hipCUB); *total = sum of all
+int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
+                              unsigned long long *total, hipStream_t stream);
+void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
+                         hipStream_t stream);
 void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,
                          hipStream_t stream);
 void launch_slot_remap(int64_t *slots, int64_t n, const int64_t *forward, hipStream_t stream);
@@ -102,7 +109,7 @@ struct EmProblem {
     unsigned int *part_flags;     // [EM_FINAL_BLOCKS] bit0 = any, bit1 = nan
     int64_t max_iters, fixed_iters;
 };
-constexpr int EM_FINAL_BLOCKS = 256;
+constexpr int EM_FINAL_BLOCKS = 1024;
 void launch_em_inner(const EmProblem &p, int parity, hipStream_t stream);
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream);
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream);

@@ -151,6 +151,25 @@ int exclusive_scan_with_total(const int64_t *in, int64_t *out, int64_t n, hipStr
 
 }  // namespace
 
+int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
+                              unsigned long long *total, hipStream_t stream)
+{
+    *total = 0;
+    if (n == 0) return 0;
+    if (n >= (1LL << 31)) return -2;
+    size_t bytes = 0;
+    QB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, stream));
+    Tmp<char> tmp;
+    QB_TRY(tmp.alloc(bytes));
+    QB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, stream));
+    unsigned long long last_in = 0, last_out = 0;
+    QB_TRY(hipMemcpyAsync(&last_in, in + n - 1, 8, hipMemcpyDeviceToHost, stream));
+    QB_TRY(hipMemcpyAsync(&last_out, out + n - 1, 8, hipMemcpyDeviceToHost, stream));
+    QB_TRY(hipStreamSynchronize(stream));
+    *total = last_in + last_out;
+    return 0;
+}
+
 int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids)
 {
     return n_tx + n_ids / EM_ROW_CAP + 1;
