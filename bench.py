@@ -110,6 +110,11 @@ def main():
     lengths = np.ascontiguousarray(index.transcripts['length'], dtype='f8')
     result = mapper.MapResult(index, device=device)
     comm_id = None
+    force_comm = world == 1 and os.environ.get('SKM_FORCE_COMM') == '1'   # 1-rank RCCL rehearsal
+    if force_comm:
+        raw = ctypes.create_string_buffer(128)
+        _native.check(hip.skm_comm_unique_id(raw))
+        comm_id = raw.raw
     if world > 1:
         import torch
         buf = torch.zeros(128, dtype=torch.uint8)
@@ -119,6 +124,9 @@ def main():
             buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
         dist.broadcast(buf, 0)
         comm_id = bytes(buf.numpy().tobytes())
+    comm = ctypes.c_void_p()
+    if comm_id is not None:                # one communicator per process, reused by every step
+        _native.check(hip.skm_comm_create(device, comm_id, rank, world, ctypes.byref(comm)))
 
     state = {}
 
@@ -133,8 +141,8 @@ def main():
         eff = result._effective_lengths(fld)
         quant = infer._QuantHandle.from_map_result(result, n_tx)
         try:
-            if world > 1:
-                _native.check(hip.skm_quant_comm_init(quant.handle, comm_id, rank, world))
+            if comm:
+                _native.check(hip.skm_quant_set_comm(quant.handle, comm))
             x = np.ones(n_tx, dtype='f8') / eff
             x /= x.sum()
             x, iters = quant.em(x, eff)
@@ -222,6 +230,8 @@ def main():
             line['cpu_baseline'] = cpu_baseline(index, pool, tx_offsets, args.seed, args.read_len,
                                                 min(args.cpu_sample, n_units))
         print(json.dumps(line), flush=True)
+    if comm:
+        _native.check(hip.skm_comm_destroy(comm))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

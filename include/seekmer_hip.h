@@ -169,10 +169,15 @@ int skm_quant_timing(skm_quant *quant, double timing[4]);
 
 /* ---------------------------------------------------------------- multi-GPU
  * Not in the reference (single process).  Reads shard across ranks; the only
- * data-path collective is one all-reduce(sum) of f64[n_tx] per EM step. */
-int skm_comm_unique_id(void *id128);                 /* rank 0: 128-byte id */
-int skm_quant_comm_init(skm_quant *quant, const void *id128, int rank, int world);
-int skm_quant_comm_destroy(skm_quant *quant);
+ * data-path collective is one all-reduce(sum) of f64[n_tx] per EM step (RCCL
+ * over xGMI), issued on the EM stream between the class pass and the
+ * finalise pass.  A communicator is created once per process and attached to
+ * every quant handle that should take part. */
+typedef struct skm_comm skm_comm;
+int skm_comm_unique_id(void *id128);                 /* rank 0: 128-byte id, single use */
+int skm_comm_create(int device, const void *id128, int rank, int world, skm_comm **out);
+int skm_comm_destroy(skm_comm *comm);
+int skm_quant_set_comm(skm_quant *quant, skm_comm *comm);   /* NULL detaches */
 
 /* ============================ libseekmer_host.so ========================== */
 

@@ -72,9 +72,10 @@ HIP_SYMBOLS = {
     'skm_quant_set_counts': (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     'skm_quant_timing': (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     'skm_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
-    'skm_quant_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                           ctypes.c_int]),
-    'skm_quant_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_comm_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                       c_void_pp]),
+    'skm_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_quant_set_comm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 HOST_SYMBOLS = {

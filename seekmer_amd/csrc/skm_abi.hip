@@ -141,10 +141,16 @@ struct skm_quant {
     DBuf<unsigned int> part_flags;
     DBuf<unsigned long long> ctl, cum, draw;
     double n_total = 0;
-    // RCCL (loaded lazily)
+    // RCCL communicator (borrowed from an skm_comm), loaded lazily
     void *comm = nullptr;
     int rank = 0, world = 1;
     double t_em_ns = 0, iters_total = 0, launches = 0;
+};
+
+struct skm_comm {
+    int device = 0;
+    void *comm = nullptr;
+    int rank = 0, world = 1;
 };
 
 // ------------------------------------------------------------------- errors
@@ -439,7 +445,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     const int64_t per_thread = (int64_t)regions * ix->d.max_target_count * 4;
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, ws_budget / (per_thread * 256)));
     m->grid_blocks = (int)blocks;
-    SKM_TRY(m->workspace.ensure((size_t)(blocks * 256) * regions * ix->d.max_target_count));
+    SKM_TRY(m->workspace.ensure((size_t)(blocks * 256) * 2 * ix->d.max_target_count));
     // entry arena: ~8 ids per unit plus one 2048-id slice of slack per wave
     SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * 4 * 2048 + 4096));
 
@@ -1096,7 +1102,6 @@ extern "C" int skm_quant_destroy(skm_quant *q)
 {
     if (!q) return SKM_OK;
     (void)hipSetDevice(q->device);
-    if (q->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(q->comm);
     (void)hipStreamSynchronize(q->stream);
     q->cls_offset.release(); q->row_start.release(); q->tx_row.release(); q->ids.release();
     q->tx_cls.release(); q->row_tx.release(); q->cls_count.release(); q->cls_count_saved.release();
@@ -1203,26 +1208,46 @@ extern "C" int skm_comm_unique_id(void *id128)
     return SKM_OK;
 }
 
-extern "C" int skm_quant_comm_init(skm_quant *q, const void *id128, int rank, int world)
+extern "C" int skm_comm_create(int device, const void *id128, int rank, int world, skm_comm **out)
 {
-    if (!q || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SKM_ERR_ARG, "bad argument");
-    std::lock_guard<std::mutex> lock(q->mu);
-    SKM_TRY(set_device(q->device));
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return fail(SKM_ERR_ARG, "bad argument");
+    int n_dev = 0;
+    SKM_TRY(skm_device_count(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(SKM_ERR_ARG, "device %d out of range", device);
+    SKM_TRY(set_device(device));
     SKM_TRY(load_rccl());
     UniqueId id;
     memcpy(&id, id128, sizeof(id));
-    NCCL_TRY(g_comm_init(&q->comm, world, id, rank));
-    q->rank = rank;
-    q->world = world;
+    skm_comm *c = new skm_comm();
+    c->device = device;
+    c->rank = rank;
+    c->world = world;
+    int r = g_comm_init(&c->comm, world, id, rank);
+    if (r != 0) {
+        delete c;
+        return fail(SKM_ERR_COMM, "ncclCommInitRank failed: %s",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    *out = c;
     return SKM_OK;
 }
 
-extern "C" int skm_quant_comm_destroy(skm_quant *q)
+extern "C" int skm_comm_destroy(skm_comm *c)
 {
-    if (!q) return SKM_OK;
+    if (!c) return SKM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->comm && g_rccl.CommDestroy) NCCL_TRY(g_rccl.CommDestroy(c->comm));
+    delete c;
+    return SKM_OK;
+}
+
+extern "C" int skm_quant_set_comm(skm_quant *q, skm_comm *c)
+{
+    if (!q) return fail(SKM_ERR_ARG, "NULL quant");
     std::lock_guard<std::mutex> lock(q->mu);
-    if (q->comm && g_rccl.CommDestroy) NCCL_TRY(g_rccl.CommDestroy(q->comm));
-    q->comm = nullptr;
-    q->world = 1;
+    if (c && c->device != q->device) return fail(SKM_ERR_ARG, "communicator and quant live on different GPUs");
+    q->comm = c ? c->comm : nullptr;
+    q->rank = c ? c->rank : 0;
+    q->world = c ? c->world : 1;
     return SKM_OK;
 }

@@ -8,8 +8,7 @@
 // ACGT" bit plane, k-mers and 8-base windows are then funnel-shifted out of
 // registers instead of being re-encoded byte by byte, contig bases are
 // fetched from a 2-bit pool, and the running target list of a lane lives in a
-// lane-interleaved HBM workspace (word i of every lane is contiguous, so the
-// lock-step part of list copies coalesces).
+// small per-lane slice of an HBM workspace.
 #include "skm_device.h"
 #include "skm_kernels.h"
 
@@ -302,9 +301,12 @@ map_units_kernel(DevIndex ix, MapBatch b)
     const int64_t total_threads = (int64_t)gridDim.x * blockDim.x;
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const size_t stride = (size_t)total_threads;
-    int32_t *const ws1 = b.workspace + gtid;
-    int32_t *const ws2 = ws1 + (size_t)ix.max_target_count * stride;
+    // each lane owns two contiguous lists (mate 1, mate 2): with lanes at
+    // different points of their state machines nothing coalesces across lanes,
+    // so a list must stay inside as few 64-byte sectors as possible
+    const size_t stride = 1;
+    int32_t *const ws1 = b.workspace + (size_t)gtid * 2 * (size_t)ix.max_target_count;
+    int32_t *const ws2 = ws1 + ix.max_target_count;
     LaneStats ls = {0, 0, 0, 0, 0, 0, 0};
     uint64_t read_bases = 0, n_reads = 0, tuple_ids = 0;
     // scheduler census (STATS build): [0]=rounds, then executions / lanes per action

@@ -7,7 +7,7 @@ while mapping; every rank holds a full index replica.  Exchange steps:
     wanted (bit-identical class counts / reference class order), the per-rank
     tables are all-gathered and merged by global first-seen unit index;
   * per EM step: one all-reduce(sum) of f64[T] -- done inside the HIP library
-    with RCCL (skm_quant_comm_init); classes stay rank-local because the EM
+    with RCCL (skm_comm_create + skm_quant_set_comm); classes stay rank-local because the EM
     numerators are linear in the class counts.
 `dist` is `torch.distributed` (backend nccl == RCCL on the GPUs, gloo in the
 CPU tests); torch is used for rendezvous and these small host-side exchanges

@@ -265,3 +265,92 @@ def test_bootstrap_draw_and_em(oracle, native_libs):
         x_ref, it_ref = oracle.em(x0, l, class_map, counts[b].astype('f8'))
         assert it_ref == iters[b]
         np.testing.assert_allclose(out[b], x_ref, rtol=1e-8, atol=1e-300)
+
+
+def test_cli_end_to_end(oracle, native_libs, chr21, chr21_oracle_index, pairs21, tmp_path):
+    """`seekmer_amd index -t` + `seekmer_amd infer -m -b 3` on the reference's
+    own test data; abundance.tsv / run_info.json / readmap.txt against the oracle."""
+    import json
+    import shutil
+    from conftest import GOLDEN
+    from seekmer_amd import __main__ as cli
+    gtf = tmp_path / 'empty.gtf'
+    gtf.write_text('')
+    index_path = tmp_path / 'index.npz'
+    assert cli.main(['index', '-t', os.path.join(GOLDEN, 'human.cdna.21.fa.bz2'), str(gtf),
+                     str(index_path)]) == 0
+    out = tmp_path / 'out'
+    assert cli.main(['infer', str(index_path), str(out), os.path.join(GOLDEN, '20_1.fastq'),
+                     os.path.join(GOLDEN, '20_2.fastq'), '-m', '-b', '3', '--seed', '7']) == 0
+
+    bases, offsets = oracle.pack_reads(pairs21)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, 21, True, fld)
+    classes = oracle.Classes()
+    classes.update(expected)
+    class_map, class_count = classes.summarize()
+    eff = oracle.effective_lengths(fld, chr21_oracle_index.lengths)
+    tpm, _ = oracle.quantify(eff, class_map, class_count)
+    est = oracle.est_counts(tpm, chr21_oracle_index.lengths, class_count.sum())
+
+    rows = [line.rstrip('\n').split('\t') for line in (out / 'abundance.tsv').open()]
+    assert rows[0] == ['target_id', 'length', 'eff_length', 'est_count', 'tpm']
+    assert len(rows) == 1 + len(chr21[0])
+    for i, row in enumerate(rows[1:]):
+        assert row[0] == chr21[0][i].decode()
+        assert row[1] == '%g' % len(chr21[1][i])
+        assert row[2] == '%g' % np.float32(eff[i])
+        assert abs(float(row[3]) - est[i]) <= 1e-4 * max(est[i], 1e-300) + 1e-6
+        assert abs(float(row[4]) - tpm[i]) <= 1e-4 * max(tpm[i], 1e-300) + 1e-6
+    info = json.load((out / 'run_info.json').open())
+    assert info['n_targets'] == len(chr21[0]) and info['n_processed'] == 21
+    assert info['n_pseudoaligned'] == 21 and info['n_bootstraps'] == 3
+    unique = sum(int(c) for k, c in enumerate(class_count)
+                 if (class_map[0] == k).sum() == 1)
+    assert info['n_unique'] == unique
+    readmap = (out / 'readmap.txt').read_text().splitlines()
+    assert len(readmap) == 21
+    tuples = expected.tuples()
+    names = [line.strip()[1:].decode() for i, line in
+             enumerate(open(os.path.join(GOLDEN, '20_1.fastq'), 'rb')) if i & 3 == 0]
+    for line, name, t in zip(readmap, names, tuples):
+        assert line.split('\t') == [name] + [chr21[0][i].decode() for i in t]
+    arrays = np.load(out / 'abundance.npz')
+    assert arrays['bootstrap/bs2'].shape == (len(chr21[0]),)
+    np.testing.assert_array_equal(arrays['aux/fld'], fld.astype('i4'))
+
+
+def test_full_size_properties(oracle, native_libs):
+    """Size-independent properties at a size the oracle would take minutes for:
+    totals, unit-order invariance of the counter, batch-split invariance,
+    single-ended fragment rule (every read counted)."""
+    from seekmer_amd import synth, index_builder, mapper, common
+    ids, pool, tx_offsets = synth.transcriptome(9, 400)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    n_units = 1_500_000
+    bases, offsets = synth.reads(9, pool, tx_offsets, 0, n_units, 100, True)
+    whole = mapper.MapResult(index)
+    mapper.ReadMapper(index, whole).map_batch(common.ReadBatch(n_units, bases, offsets, True))
+    c, rows, unaligned, total = whole.sizes()
+    offs, targets, counts, first_seen, fld = whole.export()
+    assert total == n_units and counts.sum() + unaligned == n_units
+    assert fld[0] == 0 and fld.sum() <= counts.sum()
+    assert (np.diff(first_seen) > 0).all()                    # first-seen order, unique
+    assert unaligned < 0.05 * n_units
+
+    # the same units in reverse order, in three uneven batches
+    order = np.arange(n_units)[::-1]
+    rev = bases[:-1].reshape(n_units, 200)[order].reshape(-1)
+    rev = np.concatenate([rev, np.zeros(1, dtype=np.uint8)])
+    other = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, other)
+    for lo, hi in ((0, 700_001), (700_001, 700_002), (700_002, n_units)):
+        rm.map_batch(common.ReadBatch(hi - lo, rev, np.ascontiguousarray(offsets[2 * lo:2 * hi + 1]), True))
+    assert other.sizes() == (c, rows, unaligned, total)
+    np.testing.assert_array_equal(other.fragment_length_counts, fld)
+    assert other.counter == whole.counter                      # multiset of (tuple -> count)
+
+    single = mapper.MapResult(index)
+    mapper.ReadMapper(index, single).map_batch(
+        common.ReadBatch(2 * n_units, bases, offsets, False))
+    assert single.fragment_length_counts.sum() == 2 * n_units  # every read counted
