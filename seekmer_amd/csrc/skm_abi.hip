@@ -111,6 +111,7 @@ struct skm_mapper {
     DBuf<uint64_t> codes;
     DBuf<uint32_t> acgt;
     DBuf<int32_t> workspace;
+    DBuf<char> mate1;
     DBuf<int32_t> unit_begin, unit_end, unit_count;
     DBuf<Coord> unit_anchor;
     DBuf<int64_t> unit_offset, unit_slot;
@@ -124,8 +125,8 @@ struct skm_mapper {
     int64_t host_classes = 0, host_arena_used = 0;
     bool want_stats = false;
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
-    unsigned long long stats_total[32] = {0};
-    int vote[8] = {32, 16, 16, 16, 16, 0, 0, 0};   // quorum per action of the map kernel's scheduler
+    unsigned long long stats_total[48] = {0};
+    int vote[8] = {32, 48, 32, 32, 32, 32, 0, 0};   // quorum per action (start, lookup, merge, left, right, emit)
 };
 
 struct skm_quant {
@@ -310,7 +311,7 @@ namespace {
 constexpr int CTR_ARENA = 0, CTR_CLASSES = 1, CTR_UNALIGNED = 2, CTR_UNITS = 3, CTR_LISTED = 4,
               CTR_DEFERRED = 5, CTR_FLD = 8;
 constexpr int CTR_WORDS = 8 + MAX_FRAGMENT_LENGTH;
-constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2080;
+constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2096;
 
 void bind_table(skm_mapper *m, uint64_t n_slots)
 {
@@ -437,15 +438,16 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
 
     SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
 
-    // launch geometry: at most 6 blocks of 256 lanes per CU (the kernel's
-    // occupancy), fewer when the interleaved list workspace would not fit
-    const int regions = paired ? 2 : 1;
-    int64_t blocks = std::min<int64_t>((n_units + 255) / 256, (int64_t)ix->cu_count * 6);
-    const int64_t ws_budget = 16LL << 30;
-    const int64_t per_thread = (int64_t)regions * ix->d.max_target_count * 4;
-    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, ws_budget / (per_thread * 256)));
+    // launch geometry: persistent blocks of 256 lanes, each with 512 unit contexts in LDS
+    // (~38 KB -> 4 blocks per CU); fewer blocks when the per-context list workspace
+    // (2 lists of max_target_count entries) would not fit the budget
+    constexpr int64_t CONTEXTS = 512;
+    int64_t blocks = std::min<int64_t>((n_units + CONTEXTS - 1) / CONTEXTS, (int64_t)ix->cu_count * 4);
+    // per context: mask extension words (live + staging, two mates) for slices > 64 targets
+    const int64_t ext_words = std::max<int64_t>(0, (ix->d.max_target_count + 63) / 64 - 1);
+    SKM_TRY(m->workspace.ensure((size_t)(blocks * CONTEXTS * 4 * ext_words * 2 + 16)));
+    SKM_TRY(m->mate1.ensure((size_t)(blocks * CONTEXTS) * 48));
     m->grid_blocks = (int)blocks;
-    SKM_TRY(m->workspace.ensure((size_t)(blocks * 256) * 2 * ix->d.max_target_count));
     // entry arena: ~8 ids per unit plus one 2048-id slice of slack per wave
     SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * 4 * 2048 + 4096));
 
@@ -457,6 +459,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     b.words_per_read = words;
     b.paired = paired;
     b.workspace = m->workspace.p;
+    b.mate1 = m->mate1.p;
     b.unit_begin = m->unit_begin.p;
     b.unit_end = m->unit_end.p;
     b.unit_anchor = m->unit_anchor.p;
@@ -480,17 +483,20 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         launch_map_units(ix->d, b, m->grid_blocks, m->want_stats, m->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(m->ev[2], m->stream));
-        HIP_TRY(hipMemcpyAsync(&ids, b.ids_cursor, sizeof(ids), hipMemcpyDeviceToHost, m->stream));
+        unsigned long long cursor_and_flag[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(cursor_and_flag, b.ids_cursor, sizeof(cursor_and_flag), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        ids = cursor_and_flag[0];
+        if (cursor_and_flag[1]) return fail(SKM_ERR_STATE, "map kernel: the in-kernel scheduler stalled");
         if ((int64_t)ids <= b.ids_capacity) break;
         if (attempt == 2) return fail(SKM_ERR_STATE, "entry arena overflow");
         SKM_TRY(m->unit_entries.ensure((size_t)ids + 1024));
     }
     m->last_ids = (int64_t)ids;
     if (m->want_stats) {
-        unsigned long long st[32];
+        unsigned long long st[48];
         HIP_TRY(hipMemcpy(st, b.stats, sizeof(st), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 32; ++i) m->stats_total[i] += st[i];
+        for (int i = 0; i < 48; ++i) m->stats_total[i] += st[i];
     }
 
     // class counting
@@ -558,8 +564,9 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     HIP_TRY(pool_stream_acquire(&m->stream));
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
     m->want_stats = getenv("SKM_MAP_STATS") != nullptr;
-    if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "lookup,copy,merge,align,emit"
-        sscanf(v, "%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4]);
+    if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "start,lookup,merge,left,right,emit"
+        sscanf(v, "%d,%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4],
+               &m->vote[5]);
     int rc = table_reset(m, 1 << 16);
     if (rc != SKM_OK) { delete m; return rc; }
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -575,7 +582,7 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->slots.release(); m->arena_len.release(); m->arena.release(); m->class_list.release();
     m->counters.release();
     m->error.release(); m->bases.release(); m->offsets.release(); m->codes.release();
-    m->acgt.release(); m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
+    m->acgt.release(); m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();
     m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
     m->unit_slot.release(); m->unit_claim.release(); m->claim_scan.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
@@ -818,11 +825,11 @@ extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
 // access counters of the STATS build of the map kernel (SKM_MAP_STATS=1):
 // [0]=reads [1]=read bases [2]=lookups [3]=slots [4]=contig reads [5]=targets
 // copied [6]=targets merged [7]=8-base fetches [8]=merges [9]=tuple ids
-extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[32])
+extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[48])
 {
     if (!m || !out) return fail(SKM_ERR_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(m->mu);
-    for (int i = 0; i < 32; ++i) out[i] = (int64_t)m->stats_total[i];
+    for (int i = 0; i < 48; ++i) out[i] = (int64_t)m->stats_total[i];
     return SKM_OK;
 }
 

@@ -100,21 +100,31 @@ struct LaneStats {
 };
 
 // KMerIndex.map_kmer, _common.pyx:54-97.  Home slot = hash(min(kmer, rc)) &
-// (size-1); linear probe with wrap-around; empty slot ends the probe.
+// (size-1); linear probe with wrap-around; empty slot ends the probe.  Four
+// consecutive slots are fetched per round trip (independent 16-byte loads) and
+// then examined in probe order, so a lane's probe chain costs ceil(P/4) memory
+// latencies instead of P; the slots examined -- and the result -- are the
+// reference's.
 template <bool STATS>
 __device__ __forceinline__ Coord map_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
 {
     const uint64_t rc = kmer_revcomp(kmer);
     uint32_t slot = kmer_hash(kmer < rc ? kmer : rc) & ix.slot_mask;
     if (STATS) st->lookups++;
-    for (uint32_t n = 0; n <= ix.slot_mask; ++n) {
-        const uint4 raw = *reinterpret_cast<const uint4 *>(&ix.kmers[slot]);
-        const uint64_t stored = ((uint64_t)raw.y << 32) | raw.x;
-        if (STATS) st->slots++;
-        if (stored == KMER_INVALID) return invalid_coord();
-        if (stored == kmer) return Coord{(int32_t)raw.z, (int32_t)raw.w};
-        if (stored == rc) return Coord{~(int32_t)raw.z, (int32_t)raw.w};
-        slot = (slot + 1) & ix.slot_mask;
+    for (uint64_t n = 0; n <= ix.slot_mask; n += 4) {
+        uint4 raw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            raw[j] = *reinterpret_cast<const uint4 *>(&ix.kmers[(slot + j) & ix.slot_mask]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t stored = ((uint64_t)raw[j].y << 32) | raw[j].x;
+            if (STATS) st->slots++;
+            if (stored == KMER_INVALID) return invalid_coord();
+            if (stored == kmer) return Coord{(int32_t)raw[j].z, (int32_t)raw[j].w};
+            if (stored == rc) return Coord{~(int32_t)raw[j].z, (int32_t)raw[j].w};
+        }
+        slot = (slot + 4) & ix.slot_mask;
     }
     return invalid_coord();
 }

@@ -13,7 +13,8 @@ struct MapBatch {
     int64_t n_units;
     int32_t words_per_read;
     int32_t paired;
-    int32_t *workspace;           // lane-interleaved target lists
+    int32_t *workspace;           // per-context mask extension words (slices > 64 targets)
+    void *mate1;                  // per-context parking slot of the mate-1 span and set (48 B)
     // per-unit results
     int32_t *unit_begin, *unit_end;
     Coord *unit_anchor;
@@ -25,7 +26,7 @@ struct MapBatch {
     unsigned long long *ids_cursor;
     unsigned long long *fld;      // [2000] batch-local histogram
     unsigned long long *stats;    // [16] access counters (STATS build only)
-    int32_t vote[8];              // quorum per action: lookup, copy, merge, align, emit
+    int32_t vote[8];              // quorum per action: start, lookup, merge, left, right, emit
 };
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,

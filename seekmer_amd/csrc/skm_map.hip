@@ -71,44 +71,66 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
 }
 
 // ------------------------------------------------------------------- mapper
-// Running target list of one lane: element i at p[i * stride].
-struct TList {
-    int32_t *p;
-    size_t stride;
-    __device__ __forceinline__ int32_t get(int i) const { return p[(size_t)i * stride]; }
-    __device__ __forceinline__ void set(int i, int32_t v) const { p[(size_t)i * stride] = v; }
+// Running target list of a context.  KMerIndex.map_contig (_common.pyx:143-179)
+// copies the first contig's target slice (reversed and complemented for a
+// reverse hit) and every later step only deletes entries from it
+// (_filter_on_contig, _intersect).  So the list is kept as
+//   (start, length, orientation of the slice in ix.targets) + a keep-mask,
+// element i of the reference's list being
+//   forward:  targets[start + i].entry        reverse: ~targets[start + length - 1 - i].entry
+// Nothing is copied or stored while mapping; merges are read-only walks over
+// the index (L1-cacheable).  Word 0 of the mask lives with the context, words
+// 1.. (slices longer than 64 targets) in a per-context HBM extension with a
+// staging copy of the same size behind it.
+struct TSet {
+    int32_t start;            // first element of the slice in ix.targets
+    int32_t length;           // slice length = list positions 0 .. length-1
+    bool forward;
+    uint64_t word0;
+    uint64_t *ext;            // words 1.. (live), then the staging words
+    int32_t ext_words;        // capacity of each of the two regions
+
+    __device__ __forceinline__ int words() const { return (length + 63) >> 6; }
+    __device__ __forceinline__ uint64_t word(int w) const { return w == 0 ? word0 : ext[w - 1]; }
+    __device__ __forceinline__ void set_word(int w, uint64_t v) { if (w == 0) word0 = v; else ext[w - 1] = v; }
+    __device__ __forceinline__ int32_t entry(const DevIndex &ix, int i) const
+    {
+        return forward ? ix.targets[start + i].entry : ~ix.targets[start + length - 1 - i].entry;
+    }
 };
 
-struct Span {               // MappedSpan, _common.pxd:31-35 (targets = list + n)
+struct Span {               // MappedSpan, _common.pxd:31-35 (targets = TSet, n = its size)
     int32_t begin, end;
     Coord anchor;
     int32_t n;
 };
 
-// KMerIndex.map_contig, _common.pyx:143-179.  Only `entry` of a target is ever
-// read by the mapper, so the list holds entries alone.
+// KMerIndex.map_contig, _common.pyx:143-179: the list is the whole slice
 template <bool STATS>
-__device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, const TList &list,
-                                           Span &span, LaneStats *st)
+__device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, TSet &set, Span &span, LaneStats *st)
 {
     const bool forward = c.entry >= 0;
     const int32_t index = forward ? c.entry : ~c.entry;
-    const int32_t start = (int32_t)ix.contigs[index].target_offset;
+    set.start = (int32_t)ix.contigs[index].target_offset;
     int32_t length = (int32_t)ix.contigs[index].target_length;
-    if (length > ix.max_target_count) length = ix.max_target_count;   // workspace bound
+    if (length > ix.max_target_count) length = ix.max_target_count;
+    set.length = length;
+    set.forward = forward;
     if (STATS) { st->contig_reads++; st->targets_copied += length; }
     span.n = length;
-    if (forward) {
-        for (int i = 0; i < length; ++i) list.set(i, ix.targets[start + i].entry);
-    } else {
-        for (int i = 0; i < length; ++i) list.set(i, ~ix.targets[start + length - 1 - i].entry);
+    set.word0 = 0;
+    const int words = set.words();
+    for (int w = 0; w < words; ++w) {
+        const int bits = min(64, length - 64 * w);
+        set.set_word(w, bits == 64 ? ~0ULL : ((1ULL << bits) - 1));
     }
 }
 
-// KMerIndex._filter_on_contig, _common.pyx:185-235
+// KMerIndex._filter_on_contig, _common.pyx:185-235: two-pointer merge of the
+// list (ascending signed entries) with the anchor contig's slice; an empty
+// intersection leaves the list as it was and returns false.
 template <bool STATS>
-__device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, const TList &list, Span &span,
-                                                 LaneStats *st)
+__device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, Span &span, LaneStats *st)
 {
     if (STATS) st->merges++;
     if (span.n == 0) return true;
@@ -117,27 +139,37 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, const TList
     const int32_t start = (int32_t)ix.contigs[contig].target_offset;
     const int32_t length = (int32_t)ix.contigs[contig].target_length;
     if (STATS) st->contig_reads++;
-    int read_index = 0, write_index = 0;
     int track = forward ? start : start + length - 1;
     const int bound = forward ? start + length : start - 1;
     const int step = forward ? 1 : -1;
     const int first_track = track;
-    while (read_index != span.n && track != bound) {
-        const int32_t target_entry = list.get(read_index);
-        int32_t index_entry = ix.targets[track].entry;
-        if (!forward) index_entry = ~index_entry;
-        if (target_entry == index_entry) {
-            list.set(write_index, target_entry);
-            ++read_index; ++write_index; track += step;
-        } else if (target_entry < index_entry) {
-            ++read_index;
-        } else {
-            track += step;
+    const int words = set.words();
+    uint64_t *const stage = set.ext + set.ext_words;
+    uint64_t new0 = 0;
+    int kept = 0;
+    for (int w = 0; w < words; ++w) {
+        uint64_t m = track != bound ? set.word(w) : 0, keep = 0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            const int32_t target_entry = set.entry(ix, 64 * w + bit);
+            int32_t index_entry = 0;
+            while (track != bound) {                 // skip index entries below the list entry
+                index_entry = ix.targets[track].entry;
+                if (!forward) index_entry = ~index_entry;
+                if (index_entry >= target_entry) break;
+                track += step;
+            }
+            if (track == bound) break;
+            if (index_entry == target_entry) { keep |= 1ULL << bit; ++kept; track += step; }
         }
+        if (w == 0) new0 = keep; else stage[w - 1] = keep;
     }
     if (STATS) st->targets_merged += (uint32_t)((track - first_track) * step + (track != bound ? 1 : 0));
-    if (write_index == 0) return false;
-    span.n = write_index;
+    if (kept == 0) return false;
+    set.word0 = new0;
+    for (int w = 1; w < words; ++w) set.ext[w - 1] = stage[w - 1];
+    span.n = kept;
     return true;
 }
 
@@ -231,21 +263,43 @@ __device__ __forceinline__ int right_move(const DevIndex &ix, Coord a)
     return forward ? (int)ix.contigs[contig].length - a.offset - K : a.offset;
 }
 
-// _intersect, _mapper.pyx:350-397
-__device__ __forceinline__ bool intersect(const TList &l1, Span &s1, const TList &l2, const Span &s2)
+// _intersect, _mapper.pyx:350-397: mate 1 ascending against mate 2 walked from
+// its end with complemented entries; matches are consumed one to one.
+__device__ __forceinline__ bool intersect(const DevIndex &ix, TSet &a, Span &s1, const TSet &b2, const Span &s2)
 {
     if (s1.n == 0) return true;
     if (s2.n == 0) return false;
-    int read1 = 0, write1 = 0, cursor2 = s2.n - 1;
-    while (read1 != s1.n && cursor2 != -1) {
-        const int32_t e1 = l1.get(read1);
-        const int32_t e2 = ~l2.get(cursor2);
-        if (e1 == e2) { l1.set(write1, e1); ++read1; ++write1; --cursor2; }
-        else if (e1 < e2) ++read1;
-        else --cursor2;
+    int w2 = b2.words() - 1;
+    uint64_t m2 = b2.word(w2);
+    // cursor over mate 2, highest list position first
+    auto next2 = [&](int32_t &e2) -> bool {
+        while (m2 == 0) {
+            if (w2 == 0) return false;
+            --w2;
+            m2 = b2.word(w2);
+        }
+        const int bit = 63 - __builtin_clzll(m2);
+        e2 = ~b2.entry(ix, 64 * w2 + bit);
+        return true;
+    };
+    auto drop2 = [&]() { m2 &= ~(1ULL << (63 - __builtin_clzll(m2))); };
+    int32_t e2 = 0;
+    bool have2 = next2(e2);
+    int kept = 0;
+    const int words = a.words();
+    for (int w = 0; w < words; ++w) {
+        uint64_t m = have2 ? a.word(w) : 0, keep = 0;
+        while (m && have2) {
+            const int bit = __builtin_ctzll(m);
+            const int32_t e1 = a.entry(ix, 64 * w + bit);
+            if (e1 == e2) { keep |= 1ULL << bit; ++kept; m &= m - 1; drop2(); have2 = next2(e2); }
+            else if (e1 < e2) m &= m - 1;
+            else { drop2(); have2 = next2(e2); }
+        }
+        a.set_word(w, keep);
     }
-    if (write1 == 0) return false;
-    s1.n = write1;
+    if (kept == 0) return false;
+    s1.n = kept;
     return true;
 }
 
@@ -261,88 +315,179 @@ __device__ __forceinline__ uint64_t tuple_key_step(uint64_t h, uint32_t id)
 
 // The reference maps a read with nested loops (map_read -> _find_first_kmer /
 // _filter_targets_to_left / _filter_targets_to_right, _mapper.pyx:151-343).
-// On a 64-wide wave that shape is ruinous: the 200-instruction hash sits at
-// seven call sites and the whole wave idles while a few lanes roll their
-// first k-mer past a sequencing error or take the single retry.  Here every
-// lane runs the SAME state machine, but explicitly: one round = at most one
-// index lookup per lane at ONE call site, one list merge site, one SIFT4 site
-// per direction; a lane that finishes its unit is refilled at once from its
-// wave's private unit range, so all 64 lanes keep doing useful lookups.
+// On a 64-wide wave that shape is ruinous (measured: the kernel is VALU-issue
+// bound, not memory bound): the 200-instruction hash sits at seven call sites
+// and the wave idles while a few lanes roll their first k-mer past a
+// sequencing error or take the single retry.  So the state machine is made
+// explicit and scheduled for convergence at BLOCK level:
+//   * a block keeps NCTX unit contexts (state, span, pending k-mer ...) in LDS
+//     and refills finished ones from its private range of units;
+//   * every context sits in exactly one of six per-action queues (LDS rings);
+//     each of the block's waves, on its own and without block barriers, pops
+//     up to 64 contexts from the most backed-up queue, runs that ONE action --
+//     the index lookup, the list merge, the left / right 8-base alignment
+//     step, the start of a unit or its emission, each one piece of straight
+//     code -- for all of them, and pushes every context to the queue of its
+//     next action (measured with synchronous rounds: a third of the wave time
+//     was spent at the round barrier behind the slowest chunk);
+//   * a short queue is left to fill up while other waves are still producing.
 // States that wait for a lookup result:
 //   Y_FIRST  first-hit scan (_find_first_kmer)            Y_RA  right re-anchor (:283-284)
 //   Y_LJ/Y_LS left junction / skip-a-k lookup (:247-263)  Y_RJ  right junction (:309-315)
-// States that run without a lookup:
-//   N_LEFT (:229-246, :270-275)  N_RIGHT_ENTER (:174-176)  N_RIGHT (:285-308, :335-343)
-//   N_AFTER (:177-193)  N_MATE_DONE  UNIT_DONE (map_read_pair :129-144 + batch loop :89-94)
-// Scheduling.  With 64 lanes spread over half a dozen heavy actions, running
-// every action every round keeps each at ~15 % lane utilisation (measured:
-// the kernel is VALU-issue bound, not memory bound).  So lanes WAIT in their
-// state and an action is executed only when enough lanes want it (or when it
-// is the most wanted and nothing else ran): convergence is restored by
-// voting, the price being a longer per-unit latency that the refill hides.
-enum : int { ST_IDLE = 0,
+// Other waiting states: M_* (_filter_on_contig), N_LEFT (:229-246,
+// :270-275), N_RIGHT (:285-308, :335-343), ST_NEW, ST_UNIT_DONE (map_read_pair :129-144 +
+// batch loop :89-94).  Cheap transitions (:174-193) run right after the action that
+// caused them.
+enum : int { ST_IDLE = 0, ST_NEW,
              Y_FIRST, Y_LJ, Y_LS, Y_RA, Y_RJ,          // want a lookup
-             C_COPY,                                   // want map_contig
              M_LJ, M_LS, M_RJ,                         // want a list merge
              N_LEFT, N_RIGHT,                          // want an 8-base alignment step
-             N_RIGHT_ENTER, N_AFTER, N_MATE_DONE,      // cheap transitions, run every round
+             N_RIGHT_ENTER, N_AFTER, N_MATE_DONE,      // cheap transitions
              ST_UNIT_DONE };                           // want emission
+enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, N_ACTIONS };
 
+constexpr int NCTX = 512;             // unit contexts per block (LDS)
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
+
+struct Mate1 {                        // span and target set of mate 1, parked in HBM
+    int32_t begin, end, anchor_entry, anchor_offset, n, len, set_start, set_length_fwd;
+    uint64_t word0;
+};
+constexpr int FLD_WINDOW = 512;       // fragment lengths below this are counted in LDS
+
+__device__ __forceinline__ int action_of(int state)
+{
+    if (state >= Y_FIRST && state <= Y_RJ) return A_LOOKUP;
+    if (state == ST_NEW) return A_START;
+    if (state >= M_LJ && state <= M_RJ) return A_MERGE;
+    if (state == N_LEFT) return A_LEFT;
+    if (state == N_RIGHT) return A_RIGHT;
+    return A_EMIT;                                    // ST_UNIT_DONE
+}
 
 template <bool STATS>
 __global__ void __launch_bounds__(256)
 map_units_kernel(DevIndex ix, MapBatch b)
 {
-    __shared__ uint32_t fld_lds[MAX_FRAGMENT_LENGTH];
-    for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x) fld_lds[i] = 0;
+    __shared__ uint32_t fld_lds[FLD_WINDOW];
+    // contexts, structure of arrays
+    __shared__ int32_t c_state[NCTX], c_unit[NCTX], c_begin[NCTX], c_end[NCTX], c_aentry[NCTX],
+                       c_aoffset[NCTX], c_n[NCTX], c_scan[NCTX], c_len[NCTX], c_tstart[NCTX],
+                       c_tlen[NCTX];
+    __shared__ uint32_t c_kmer_lo[NCTX], c_kmer_hi[NCTX], c_mask_lo[NCTX], c_mask_hi[NCTX];
+    // one MPMC ring per action: entry = context | 0x8000 once written, 0 while empty
+    __shared__ uint16_t ring[N_ACTIONS][NCTX];
+    __shared__ uint32_t q_head[N_ACTIONS], q_tail[N_ACTIONS], next_unit, done_units, busy, stalled;
+
+    for (int i = threadIdx.x; i < FLD_WINDOW; i += blockDim.x) fld_lds[i] = 0;
+    for (int i = threadIdx.x; i < N_ACTIONS * NCTX; i += blockDim.x) (&ring[0][0])[i] = 0;
+    if (threadIdx.x < N_ACTIONS) { q_head[threadIdx.x] = 0; q_tail[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { next_unit = 0; done_units = 0; busy = 0; stalled = 0; }
     __syncthreads();
 
-    const int64_t total_threads = (int64_t)gridDim.x * blockDim.x;
-    const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    // each lane owns two contiguous lists (mate 1, mate 2): with lanes at
-    // different points of their state machines nothing coalesces across lanes,
-    // so a list must stay inside as few 64-byte sectors as possible
-    const size_t stride = 1;
-    int32_t *const ws1 = b.workspace + (size_t)gtid * 2 * (size_t)ix.max_target_count;
-    int32_t *const ws2 = ws1 + ix.max_target_count;
+    // this block's private range of units: no global atomics for work distribution
+    const int64_t per_block = (b.n_units + gridDim.x - 1) / gridDim.x;
+    const int64_t block_first = blockIdx.x * per_block;
+    const int64_t block_units = max((int64_t)0, min(b.n_units, block_first + per_block) - block_first);
+    // mask extension words (live + staging, per mate) for slices longer than 64 targets
+    const int ext_words = max(0, (ix.max_target_count + 63) / 64 - 1);
+    uint64_t *const ws_block = reinterpret_cast<uint64_t *>(b.workspace)
+                               + (size_t)blockIdx.x * NCTX * 4 * (size_t)ext_words;
+    Mate1 *const mate1_block = reinterpret_cast<Mate1 *>(b.mate1) + (size_t)blockIdx.x * NCTX;
+    int64_t chunk_pos = 0, chunk_end = 0;      // wave-uniform slice of the entry arena
     LaneStats ls = {0, 0, 0, 0, 0, 0, 0};
     uint64_t read_bases = 0, n_reads = 0, tuple_ids = 0;
-    // scheduler census (STATS build): [0]=rounds, then executions / lanes per action
-    uint32_t census[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t census[1 + 2 * N_ACTIONS];
+    for (int i = 0; i < 1 + 2 * N_ACTIONS; ++i) census[i] = 0;
+    // cycle stamps (STATS build): [0]=idle / choosing [1]=unused [2..]=per action
+    unsigned long long cyc[2 + N_ACTIONS];
+    for (int i = 0; i < 2 + N_ACTIONS; ++i) cyc[i] = 0;
+    unsigned long long t_mark = STATS ? clock64() : 0;
 
-    // this wave's private range of units: no atomics for work distribution
-    const int64_t n_waves = total_threads >> 6;
-    const int64_t per_wave = (b.n_units + n_waves - 1) / n_waves;
-    int64_t next = (gtid >> 6) * per_wave;
-    const int64_t limit = min(b.n_units, next + per_wave);
-    int64_t chunk_pos = 0, chunk_end = 0;      // wave-uniform slice of the entry arena
-    const int th_lookup = b.vote[0], th_copy = b.vote[1], th_merge = b.vote[2],
-              th_align = b.vote[3], th_emit = b.vote[4];
+    // seed: every context takes a unit and queues up for A_START
+    for (int c = threadIdx.x; c < NCTX; c += blockDim.x) {
+        const uint32_t k = atomicAdd(&next_unit, 1u);
+        if ((int64_t)k < block_units) {
+            c_unit[c] = (int32_t)k;
+            c_state[c] = ST_NEW;
+            ring[A_START][atomicAdd(&q_tail[A_START], 1u) % NCTX] = (uint16_t)(c | 0x8000);
+        }
+    }
+    __syncthreads();
 
-    // per-lane machine state
-    int state = ST_IDLE;
-    int64_t u = 0;
-    int mate = 0, attempt = 0, scan_i = 0, len1 = 0;
-    uint64_t kmer = 0;
-    ReadView rv{b.codes, b.acgt, 0};
-    Span span{0, 0, invalid_coord(), 0};
-    Span s1 = span;
-
+    uint32_t idle_spins = 0;
     for (;;) {
-        // ---------------------------------------------------------- refill
-        const unsigned long long idle = __ballot(state == ST_IDLE);
-        if (idle != 0 && next < limit) {
-            const int rank = __popcll(idle & ((1ULL << lane) - 1));
-            if (state == ST_IDLE && next + rank < limit) {
-                u = next + rank;
-                mate = 0;
-                attempt = 0;
-                const int64_t r = b.paired ? 2 * u : u;
+        // ------------------------------------------------ pick the most backed-up action
+        int action = -1;
+        uint32_t avail = 0, head = 0;
+        for (int a = 0; a < N_ACTIONS; ++a) {
+            const uint32_t h = *(volatile uint32_t *)&q_head[a];
+            const uint32_t t = *(volatile uint32_t *)&q_tail[a];
+            if (t - h > avail && (int)(t - h) >= 0) { avail = t - h; action = a; head = h; }
+        }
+        if (*(volatile uint32_t *)&stalled) break;        // a bounded spin gave up: drain, host reports it
+        if (avail == 0) {
+            if (*(volatile uint32_t *)&done_units >= (uint32_t)block_units) break;
+            if (++idle_spins > (1u << 26)) { stalled = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        // a short queue is worth waiting for while other waves are still producing
+        if ((int)avail < b.vote[action] && *(volatile uint32_t *)&busy != 0) {
+            if (++idle_spins > (1u << 26)) { stalled = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        idle_spins = 0;
+        const uint32_t take = avail < 64u ? avail : 64u;
+        uint32_t won = 0;
+        if (lane == 0) {
+            won = atomicCAS(&q_head[action], head, head + take) == head;
+            if (won) atomicAdd(&busy, 1u);
+        }
+        if (!__shfl(won, 0, 64)) continue;
+        if (STATS) { const unsigned long long t = clock64(); cyc[0] += t - t_mark; t_mark = t; }
+        const bool valid = (uint32_t)lane < take;
+        if (STATS && lane == 0) { census[0]++; census[1 + 2 * action]++; census[2 + 2 * action] += take; }
+        int c = 0;
+        if (valid) {
+            volatile uint16_t *slot = &ring[action][(head + lane) % NCTX];
+            uint16_t e;
+            uint32_t spins = 0;
+            do { e = *slot; } while (!(e & 0x8000) && ++spins < (1u << 24));   // reserved by a producer, written in a moment
+            if (!(e & 0x8000)) stalled = 1;
+            *slot = 0;
+            c = e & 0x7fff;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int next_action = -1;                             // queue the context goes to afterwards
+        {
+            const unsigned long long t_action = STATS ? clock64() : 0;
+            // load the context
+            int word = valid ? c_state[c] : ST_IDLE;
+            int state = word & 0xff, mate = (word >> 8) & 1, attempt = (word >> 9) & 1;
+            const int64_t u = block_first + c_unit[c];
+            Span span{c_begin[c], c_end[c], Coord{c_aentry[c], c_aoffset[c]}, c_n[c]};
+            int scan_i = c_scan[c];
+            uint64_t kmer = ((uint64_t)c_kmer_hi[c] << 32) | c_kmer_lo[c];
+            uint64_t *const ext1 = ws_block + (size_t)c * 4 * (size_t)ext_words;
+            uint64_t *const ext2 = ext1 + 2 * (size_t)ext_words;
+            TSet set{c_tstart[c], c_tlen[c] >> 1, (c_tlen[c] & 1) != 0,
+                     ((uint64_t)c_mask_hi[c] << 32) | c_mask_lo[c], mate ? ext2 : ext1, ext_words};
+            ReadView rv;
+            {
+                const int64_t r = b.paired ? 2 * u + mate : u;
                 rv.codes = b.codes + r * b.words_per_read;
                 rv.acgt = b.acgt + r * b.words_per_read;
+                rv.len = c_len[c];
+            }
+
+            if (valid && action == A_START) {
+                const int64_t r = b.paired ? 2 * u : u;
                 rv.len = (int)(b.offsets[r + 1] - b.offsets[r]);
+                mate = 0;
+                attempt = 0;
                 span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
                 if (STATS) { read_bases += rv.len; n_reads++; }
                 if (rv.len < K) {
@@ -352,37 +497,237 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     scan_i = K;
                     state = Y_FIRST;
                 }
-            }
-            next += __popcll(idle);
-        }
-        if (__ballot(state != ST_IDLE) == 0) break;
-
-        // ------------------------------------------------ cheap transitions
-        while (__ballot(state >= N_RIGHT_ENTER && state <= N_MATE_DONE) != 0) {
-            if (state == N_RIGHT_ENTER) {                 // map_read, :174-176 / :190-192
-                if (span.n != 0 && span.end < rv.len - K) {
-                    kmer = read_kmer(rv, span.end);
-                    state = Y_RA;
-                } else {
+            } else if (valid && action == A_LOOKUP) {
+                // ---------------------------------- the one index lookup site
+                const Coord pos = map_kmer<STATS>(ix, kmer, &ls);
+                span.anchor = pos;
+                if (state == Y_FIRST) {                       // _find_first_kmer, :199-216
+                    if (pos.offset >= 0) {
+                        span.begin = scan_i - K;
+                        span.end = span.begin;
+                        map_contig<STATS>(ix, pos, set, span, &ls);
+                        state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+                    } else if (scan_i < rv.len) {
+                        kmer = ((kmer << 2) | read_code(rv, scan_i)) & KMER_MASK;     // _kmer.append
+                        ++scan_i;
+                    } else {
+                        state = N_MATE_DONE;                  // no hit: returned as is, no retry
+                    }
+                } else if (state == Y_RA) {
+                    state = N_RIGHT;
+                } else if (pos.offset >= 0) {
+                    state = state == Y_LJ ? M_LJ : (state == Y_LS ? M_LS : M_RJ);
+                } else if (state == Y_LJ) {                   // miss at the junction, :250-259
+                    if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
+                } else {                                      // Y_LS :260-263, Y_RJ :312-315
+                    span.n = 0;
                     state = N_AFTER;
                 }
-            } else if (state == N_AFTER) {
-                if (span.n != 0 || attempt == 1) {
-                    state = N_MATE_DONE;
-                } else {                                  // the single retry, :179-185
-                    attempt = 1;
-                    span.anchor = invalid_coord();
-                    span.begin += K;
-                    if (span.begin + K > rv.len) span.begin = rv.len - K;
-                    span.end = span.begin;
-                    kmer = read_kmer(rv, span.begin);
-                    scan_i = span.begin + K;
-                    state = Y_FIRST;
+            } else if (valid && action == A_MERGE) {
+                // ---------------------------------- the one _filter_on_contig site
+                const bool ok = filter_on_contig<STATS>(ix, set, span, &ls);
+                if (state == M_LJ) {
+                    if (ok) state = N_LEFT;
+                    else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
+                } else if (state == M_LS) {
+                    if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
+                } else {
+                    if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
                 }
-            } else if (state == N_MATE_DONE) {
-                if (b.paired && mate == 0) {
-                    s1 = span;
-                    len1 = rv.len;
+            } else if (valid && action == A_LEFT) {
+                // --------------- _filter_targets_to_left: loop head + alignment step
+                const bool forward = span.anchor.entry >= 0;
+                const int move = left_move(ix, span.anchor);
+                if (STATS) ls.contig_reads++;
+                const bool in_loop = span.begin > move;
+                int at;
+                if (in_loop) {
+                    span.begin -= move;
+                    span.anchor.offset -= forward ? move : -move;
+                    at = span.begin;
+                } else {                                      // closing check, :270-275
+                    span.anchor.offset -= forward ? span.begin : -span.begin;
+                    at = 0;
+                }
+                const int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
+                if (!in_loop) {
+                    if (shift == INVALID_SHIFT) span.n = 0;
+                    state = N_RIGHT_ENTER;
+                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                    span.n = 0;
+                    state = N_AFTER;
+                } else {
+                    span.begin -= shift + 1;
+                    if (span.begin < 0) {
+                        span.begin = 0;
+                        state = N_RIGHT_ENTER;
+                    } else {
+                        kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)          // _kmer.prepend
+                               | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
+                        state = Y_LJ;
+                    }
+                }
+            } else if (valid && action == A_RIGHT) {
+                // -------------- _filter_targets_to_right: loop head + alignment step
+                const bool forward = span.anchor.entry >= 0;
+                const int move = right_move(ix, span.anchor);
+                if (STATS) ls.contig_reads++;
+                const int rest = rv.len - span.end - K;
+                const bool in_loop = rest > move;
+                int at;
+                if (in_loop) {
+                    span.end += move;
+                    span.anchor.offset += forward ? move : -move;
+                    at = span.end + K - ALIGN_LENGTH;
+                } else {                                      // closing check, :335-343
+                    span.anchor.offset += forward ? rest : -rest;
+                    at = rv.len - ALIGN_LENGTH;
+                }
+                const int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
+                if (!in_loop) {
+                    if (shift == INVALID_SHIFT) span.n = 0;
+                    state = N_AFTER;
+                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                    span.n = 0;
+                    state = N_AFTER;
+                } else {
+                    span.end += shift + 1;
+                    if (span.end + K > rv.len) {
+                        span.end = rv.len - K;
+                        state = N_AFTER;
+                    } else {
+                        kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)          // _kmer.append
+                                | read_code(rv, span.end + K - 1)) & KMER_MASK;
+                        state = Y_RJ;
+                    }
+                }
+            } else if (action == A_EMIT) {
+                // ---------------------------------------------- A_EMIT: finished units
+                int n_out = 0;
+                if (valid) {
+                    if (b.paired) {
+                        // map_read_pair, _mapper.pyx:129-144 (span/set = mate 2, parked = mate 1)
+                        const Mate1 m1 = mate1_block[c];
+                        Span s1{m1.begin, m1.end, Coord{m1.anchor_entry, m1.anchor_offset}, m1.n};
+                        TSet set1{m1.set_start, m1.set_length_fwd >> 1, (m1.set_length_fwd & 1) != 0,
+                                  m1.word0, ext1, ext_words};
+                        const Span s2 = span;
+                        if (!intersect(ix, set1, s1, set, s2)) {
+                            s1.n = 0;
+                            s1.begin = 0;
+                            s1.end = -K;
+                        } else if (s1.anchor.entry != ~s2.anchor.entry) {
+                            s1.begin = 0;
+                            s1.end = -K;
+                        } else {
+                            int interval = s2.anchor.offset - s1.anchor.offset;
+                            if (s1.anchor.entry < 0) interval = -interval;
+                            s1.end = (m1.len - K) + interval + (rv.len - K) - s2.begin;
+                        }
+                        span = s1;
+                        set = set1;
+                    }
+                    // fragment length rule, _mapper.pyx:90-94
+                    int length = span.end - span.begin + K;
+                    if (length > 0) {
+                        if (length >= MAX_FRAGMENT_LENGTH) length = MAX_FRAGMENT_LENGTH - 1;
+                        if (length < FLD_WINDOW) atomicAdd(&fld_lds[length], 1u);
+                        else atomicAdd(&b.fld[length], 1ULL);
+                    }
+                    n_out = span.n;
+                }
+                // one slice of the entry arena for the whole chunk
+                int scan = n_out;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(scan, d, 64);
+                    if (lane >= d) scan += up;
+                }
+                const int wave_total = __shfl(scan, 63, 64);
+                if (chunk_pos + wave_total > chunk_end) {
+                    const int64_t want = wave_total > ARENA_CHUNK ? wave_total : ARENA_CHUNK;
+                    unsigned long long got = 0;
+                    if (lane == 0) got = atomicAdd(b.ids_cursor, (unsigned long long)want);
+                    chunk_pos = (int64_t)__shfl(got, 0, 64);
+                    chunk_end = chunk_pos + want;
+                }
+                if (valid) {
+                    const int64_t off = chunk_pos + scan - n_out;
+                    uint64_t key = 0x243F6A8885A308D3ULL ^ (uint64_t)n_out;
+                    const bool fits = off + n_out <= b.ids_capacity;
+                    int i = 0;
+                    const int words = n_out ? set.words() : 0;
+                    for (int w = 0; w < words; ++w) {
+                        uint64_t m = set.word(w);
+                        while (m) {
+                            const int32_t e = set.entry(ix, 64 * w + __builtin_ctzll(m));
+                            m &= m - 1;
+                            if (fits) b.unit_entries[off + i] = e;
+                            key = tuple_key_step(key, (uint32_t)(e < 0 ? ~e : e));   // _get_ids, :533-536
+                            ++i;
+                        }
+                    }
+                    if (key == 0) key = 1;
+                    b.unit_offset[u] = off;
+                    b.unit_count[u] = n_out;
+                    b.unit_key[u] = n_out ? key : 0;
+                    b.unit_begin[u] = span.begin;
+                    b.unit_end[u] = span.end;
+                    b.unit_anchor[u] = span.anchor;
+                    if (STATS) tuple_ids += n_out;
+                }
+                chunk_pos += wave_total;
+                // each of these contexts takes the block's next unit, or retires
+                const unsigned long long finished = __ballot(valid);
+                uint32_t base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&next_unit, (uint32_t)__popcll(finished));
+                    atomicAdd(&done_units, (uint32_t)__popcll(finished));
+                }
+                base = __shfl(base, 0, 64);
+                if (valid) {
+                    const uint32_t k = base + __popcll(finished & ((1ULL << lane) - 1));
+                    if ((int64_t)k < block_units) {
+                        c_unit[c] = (int32_t)k;
+                        c_state[c] = ST_NEW;
+                        next_action = A_START;
+                    } else {
+                        c_state[c] = ST_IDLE;
+                    }
+                }
+            }
+
+            // ------------------------------ cheap transitions until the context waits again
+            while (valid && action != A_EMIT && state >= N_RIGHT_ENTER && state <= N_MATE_DONE) {
+                if (state == N_RIGHT_ENTER) {                 // map_read, :174-176 / :190-192
+                    if (span.n != 0 && span.end < rv.len - K) {
+                        kmer = read_kmer(rv, span.end);
+                        state = Y_RA;
+                    } else {
+                        state = N_AFTER;
+                    }
+                } else if (state == N_AFTER) {
+                    if (span.n != 0 || attempt == 1) {
+                        state = N_MATE_DONE;
+                    } else {                                  // the single retry, :179-185
+                        attempt = 1;
+                        span.anchor = invalid_coord();
+                        span.begin += K;
+                        if (span.begin + K > rv.len) span.begin = rv.len - K;
+                        span.end = span.begin;
+                        kmer = read_kmer(rv, span.begin);
+                        scan_i = span.begin + K;
+                        state = Y_FIRST;
+                    }
+                } else if (b.paired && mate == 0) {           // N_MATE_DONE: on to mate 2
+                    mate1_block[c] = Mate1{span.begin, span.end, span.anchor.entry, span.anchor.offset,
+                                           span.n, rv.len, set.start, (set.length << 1) | (set.forward ? 1 : 0),
+                                           set.word0};
+                    set.ext = ext2;
+                    set.length = 0;
+                    set.word0 = 0;
                     mate = 1;
                     attempt = 0;
                     const int64_t r = 2 * u + 1;
@@ -395,233 +740,57 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         kmer = read_kmer(rv, 0);
                         scan_i = K;
                         state = Y_FIRST;
-                    }                                     // else: stays N_MATE_DONE, closed next pass
+                    } else {
+                        state = ST_UNIT_DONE;                 // mate 2 shorter than k: unmapped
+                    }
                 } else {
                     state = ST_UNIT_DONE;
                 }
             }
+
+            // store the context
+            if (valid && action != A_EMIT) {
+                c_state[c] = state | (mate << 8) | (attempt << 9);
+                c_begin[c] = span.begin;
+                c_end[c] = span.end;
+                c_aentry[c] = span.anchor.entry;
+                c_aoffset[c] = span.anchor.offset;
+                c_n[c] = span.n;
+                c_scan[c] = scan_i;
+                c_len[c] = rv.len;
+                c_kmer_lo[c] = (uint32_t)kmer;
+                c_kmer_hi[c] = (uint32_t)(kmer >> 32);
+                c_tstart[c] = set.start;
+                c_tlen[c] = (set.length << 1) | (set.forward ? 1 : 0);
+                c_mask_lo[c] = (uint32_t)set.word0;
+                c_mask_hi[c] = (uint32_t)(set.word0 >> 32);
+                next_action = action_of(state);
+            }
+            if (STATS) cyc[2 + action] += clock64() - t_action;
         }
-
-        // --------------------------------------------------------- the vote
-        const int n_lookup = __popcll(__ballot(state >= Y_FIRST && state <= Y_RJ));
-        const int n_copy = __popcll(__ballot(state == C_COPY));
-        const int n_merge = __popcll(__ballot(state >= M_LJ && state <= M_RJ));
-        const int n_left = __popcll(__ballot(state == N_LEFT));
-        const int n_right = __popcll(__ballot(state == N_RIGHT));
-        const int n_emit = __popcll(__ballot(state == ST_UNIT_DONE));
-        bool do_lookup = n_lookup >= th_lookup, do_copy = n_copy >= th_copy,
-             do_merge = n_merge >= th_merge, do_left = n_left >= th_align,
-             do_right = n_right >= th_align, do_emit = n_emit >= th_emit;
-        if (!(do_lookup || do_copy || do_merge || do_left || do_right || do_emit)) {
-            // nothing reached its quorum: run the most wanted action
-            const int best = max(max(max(n_lookup, n_copy), max(n_merge, n_left)), max(n_right, n_emit));
-            if (n_lookup == best) do_lookup = true;
-            else if (n_merge == best) do_merge = true;
-            else if (n_left == best) do_left = true;
-            else if (n_right == best) do_right = true;
-            else if (n_copy == best) do_copy = true;
-            else do_emit = true;
-        }
-
-        if (STATS) {
-            census[0]++;
-            if (do_lookup) { census[1]++; census[2] += n_lookup; }
-            if (do_copy) { census[3]++; census[4] += n_copy; }
-            if (do_merge) { census[5]++; census[6] += n_merge; }
-            if (do_left) { census[7]++; census[8] += n_left; }
-            if (do_right) { census[9]++; census[10] += n_right; }
-            if (do_emit) { census[11]++; census[12] += n_emit; }
-        }
-
-        const TList list{mate ? ws2 : ws1, stride};
-
-        // ------------------------------------------ the one index lookup site
-        if (do_lookup && state >= Y_FIRST && state <= Y_RJ) {
-            const Coord pos = map_kmer<STATS>(ix, kmer, &ls);
-            span.anchor = pos;
-            if (state == Y_FIRST) {                       // _find_first_kmer, :199-216
-                if (pos.offset >= 0) {
-                    span.begin = scan_i - K;
-                    span.end = span.begin;
-                    state = C_COPY;
-                } else if (scan_i < rv.len) {
-                    kmer = ((kmer << 2) | read_code(rv, scan_i)) & KMER_MASK;     // _kmer.append
-                    ++scan_i;
-                } else {
-                    state = N_MATE_DONE;                  // no hit: returned as is, no retry
-                }
-            } else if (state == Y_RA) {
-                state = N_RIGHT;
-            } else if (pos.offset >= 0) {
-                state = state == Y_LJ ? M_LJ : (state == Y_LS ? M_LS : M_RJ);
-            } else if (state == Y_LJ) {                   // miss at the junction, :250-259
-                if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
-                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
-            } else {                                      // Y_LS :260-263, Y_RJ :312-315
-                span.n = 0;
-                state = N_AFTER;
+        // ------------------------------------------------ hand every context to its next queue
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (int a = 0; a < N_ACTIONS; ++a) {
+            const unsigned long long going = __ballot(next_action == a);
+            if (going == 0) continue;
+            const int leader = __builtin_ctzll(going);
+            uint32_t pos = 0;
+            if (lane == leader) pos = atomicAdd(&q_tail[a], (uint32_t)__popcll(going));
+            pos = __shfl(pos, leader, 64);
+            if (next_action == a) {
+                volatile uint16_t *slot = &ring[a][(pos + __popcll(going & ((1ULL << lane) - 1))) % NCTX];
+                uint32_t spins = 0;
+                while (*slot != 0 && ++spins < (1u << 24)) { }   // (a reader that reserved it is about to clear it)
+                if (*slot != 0) stalled = 1;
+                *slot = (uint16_t)(c | 0x8000);
             }
         }
-
-        // ---------------------------------------------- KMerIndex.map_contig
-        if (do_copy && state == C_COPY) {
-            map_contig<STATS>(ix, span.anchor, list, span, &ls);
-            state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
-        }
-
-        // ------------------------------------- the one _filter_on_contig site
-        if (do_merge && state >= M_LJ && state <= M_RJ) {
-            const bool ok = filter_on_contig<STATS>(ix, list, span, &ls);
-            if (state == M_LJ) {
-                if (ok) state = N_LEFT;
-                else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
-                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
-            } else if (state == M_LS) {
-                if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
-            } else {
-                if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
-            }
-        }
-
-        // ------------------- _filter_targets_to_left: loop head + alignment step
-        if (do_left && state == N_LEFT) {
-            const bool forward = span.anchor.entry >= 0;
-            const int move = left_move(ix, span.anchor);
-            if (STATS) ls.contig_reads++;
-            const bool in_loop = span.begin > move;
-            int at;
-            if (in_loop) {
-                span.begin -= move;
-                span.anchor.offset -= forward ? move : -move;
-                at = span.begin;
-            } else {                                      // closing check, :270-275
-                span.anchor.offset -= forward ? span.begin : -span.begin;
-                at = 0;
-            }
-            const int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
-            if (!in_loop) {
-                if (shift == INVALID_SHIFT) span.n = 0;
-                state = N_RIGHT_ENTER;
-            } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
-                span.n = 0;
-                state = N_AFTER;
-            } else {
-                span.begin -= shift + 1;
-                if (span.begin < 0) {
-                    span.begin = 0;
-                    state = N_RIGHT_ENTER;
-                } else {
-                    kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)          // _kmer.prepend
-                           | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
-                    state = Y_LJ;
-                }
-            }
-        }
-
-        // ------------------ _filter_targets_to_right: loop head + alignment step
-        if (do_right && state == N_RIGHT) {
-            const bool forward = span.anchor.entry >= 0;
-            const int move = right_move(ix, span.anchor);
-            if (STATS) ls.contig_reads++;
-            const int rest = rv.len - span.end - K;
-            const bool in_loop = rest > move;
-            int at;
-            if (in_loop) {
-                span.end += move;
-                span.anchor.offset += forward ? move : -move;
-                at = span.end + K - ALIGN_LENGTH;
-            } else {                                      // closing check, :335-343
-                span.anchor.offset += forward ? rest : -rest;
-                at = rv.len - ALIGN_LENGTH;
-            }
-            const int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
-            if (!in_loop) {
-                if (shift == INVALID_SHIFT) span.n = 0;
-                state = N_AFTER;
-            } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
-                span.n = 0;
-                state = N_AFTER;
-            } else {
-                span.end += shift + 1;
-                if (span.end + K > rv.len) {
-                    span.end = rv.len - K;
-                    state = N_AFTER;
-                } else {
-                    kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)          // _kmer.append
-                            | read_code(rv, span.end + K - 1)) & KMER_MASK;
-                    state = Y_RJ;
-                }
-            }
-        }
-
-        // --------------------------------------------------- finished units
-        if (!do_emit) continue;
-        int n_out = 0;
-        if (state == ST_UNIT_DONE) {
-            if (b.paired) {
-                // map_read_pair, _mapper.pyx:129-144 (span = mate 2, s1 = mate 1)
-                const TList l1{ws1, stride}, l2{ws2, stride};
-                const Span s2 = span;
-                if (!intersect(l1, s1, l2, s2)) {
-                    s1.n = 0;
-                    s1.begin = 0;
-                    s1.end = -K;
-                } else if (s1.anchor.entry != ~s2.anchor.entry) {
-                    s1.begin = 0;
-                    s1.end = -K;
-                } else {
-                    int interval = s2.anchor.offset - s1.anchor.offset;
-                    if (s1.anchor.entry < 0) interval = -interval;
-                    s1.end = (len1 - K) + interval + (rv.len - K) - s2.begin;
-                }
-                span = s1;
-            }
-            // fragment length rule, _mapper.pyx:90-94
-            int length = span.end - span.begin + K;
-            if (length > 0) {
-                if (length >= MAX_FRAGMENT_LENGTH) length = MAX_FRAGMENT_LENGTH - 1;
-                atomicAdd(&fld_lds[length], 1u);
-            }
-            n_out = span.n;
-        }
-        // one slice of the entry arena for all lanes that finish this round
-        int scan = n_out;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(scan, d, 64);
-            if (lane >= d) scan += up;
-        }
-        const int wave_total = __shfl(scan, 63, 64);
-        if (chunk_pos + wave_total > chunk_end) {
-            const int64_t want = wave_total > ARENA_CHUNK ? wave_total : ARENA_CHUNK;
-            unsigned long long got = 0;
-            if (lane == 0) got = atomicAdd(b.ids_cursor, (unsigned long long)want);
-            chunk_pos = (int64_t)__shfl(got, 0, 64);
-            chunk_end = chunk_pos + want;
-        }
-        if (state == ST_UNIT_DONE) {
-            const int64_t off = chunk_pos + scan - n_out;
-            uint64_t key = 0x243F6A8885A308D3ULL ^ (uint64_t)n_out;
-            const bool fits = off + n_out <= b.ids_capacity;
-            for (int i = 0; i < n_out; ++i) {
-                const int32_t e = ws1[(size_t)i * stride];
-                if (fits) b.unit_entries[off + i] = e;
-                key = tuple_key_step(key, (uint32_t)(e < 0 ? ~e : e));   // _get_ids, :533-536
-            }
-            if (key == 0) key = 1;
-            b.unit_offset[u] = off;
-            b.unit_count[u] = n_out;
-            b.unit_key[u] = n_out ? key : 0;
-            b.unit_begin[u] = span.begin;
-            b.unit_end[u] = span.end;
-            b.unit_anchor[u] = span.anchor;
-            if (STATS) tuple_ids += n_out;
-            state = ST_IDLE;
-        }
-        chunk_pos += wave_total;
+        if (lane == 0) atomicSub(&busy, 1u);
+        if (STATS) t_mark = clock64();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x)
+    if (threadIdx.x == 0 && stalled) atomicExch(b.ids_cursor + 1, 1ULL);   // scheduler gave up
+    for (int i = threadIdx.x; i < FLD_WINDOW; i += blockDim.x)
         if (fld_lds[i]) atomicAdd(&b.fld[i], (unsigned long long)fld_lds[i]);
     if (STATS) {
         unsigned long long *o = b.stats;
@@ -635,8 +804,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
         atomicAdd(&o[7], (unsigned long long)ls.seq_fetches);
         atomicAdd(&o[8], (unsigned long long)ls.merges);
         atomicAdd(&o[9], (unsigned long long)tuple_ids);
-        if (lane == 0)
-            for (int i = 0; i < 13; ++i) atomicAdd(&o[16 + i], (unsigned long long)census[i]);
+        if (lane == 0) {
+            for (int i = 0; i < 1 + 2 * N_ACTIONS; ++i) atomicAdd(&o[16 + i], (unsigned long long)census[i]);
+            for (int i = 0; i < 2 + N_ACTIONS; ++i) atomicAdd(&o[32 + i], cyc[i]);
+        }
     }
 }
 

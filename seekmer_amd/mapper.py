@@ -229,15 +229,17 @@ class MapResult:
         _native.check(_native.hip().skm_mapper_set_stats(self._handle, int(bool(enable))))
 
     def access_stats(self):
-        out = (ctypes.c_int64 * 32)()
+        out = (ctypes.c_int64 * 48)()
         _native.check(_native.hip().skm_mapper_access_stats(self._handle, out))
         names = ('reads', 'read_bases', 'lookups', 'slots', 'contig_reads', 'targets_copied',
                  'targets_merged', 'seq_fetches', 'merges', 'tuple_ids')
         stats = {n: int(out[i]) for i, n in enumerate(names)}
-        census = ('rounds', 'lookup_exec', 'lookup_lanes', 'copy_exec', 'copy_lanes', 'merge_exec',
-                  'merge_lanes', 'left_exec', 'left_lanes', 'right_exec', 'right_lanes',
-                  'emit_exec', 'emit_lanes')
+        census = ('rounds', 'start_exec', 'start_lanes', 'lookup_exec', 'lookup_lanes', 'merge_exec',
+                  'merge_lanes', 'left_exec', 'left_lanes', 'right_exec', 'right_lanes', 'emit_exec',
+                  'emit_lanes')
         stats['census'] = {n: int(out[16 + i]) for i, n in enumerate(census)}
+        cycles = ('schedule', 'barrier', 'start', 'lookup', 'merge', 'left', 'right', 'emit')
+        stats['wave_cycles'] = {n: int(out[32 + i]) for i, n in enumerate(cycles)}
         return stats
 
     def timing(self):
