@@ -54,6 +54,11 @@ int skm_device_free(int device, void *ptr);
 int skm_device_upload(int device, void *dst, const void *src, int64_t bytes);
 int skm_device_download(int device, void *dst, const void *src, int64_t bytes);
 int skm_device_synchronize(int device);
+/* Diagnostic: rate of random 16-byte gathers over a table of `table_bytes`
+ * (power of two); chain=0 independent (throughput), chain=1 dependent
+ * (latency under load).  The ceiling the index probes are priced against. */
+int skm_device_gather_ceiling(int device, int64_t table_bytes, int blocks, int per_lane,
+                              int chain, double *gathers_per_second);
 
 /* ------------------------------------------------------------------ index
  * Replaces the memoryview binding of KMerIndex.__init__

@@ -36,6 +36,8 @@ HIP_SYMBOLS = {
     'skm_device_upload': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_i64]),
     'skm_device_download': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_i64]),
     'skm_device_synchronize': (ctypes.c_int, [ctypes.c_int]),
+    'skm_device_gather_ceiling': (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, c_f64p]),
     'skm_index_create': (ctypes.c_int, [ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_int, c_void_pp]),

@@ -108,8 +108,7 @@ struct skm_mapper {
     // batch buffers
     DBuf<uint8_t> bases;
     DBuf<int64_t> offsets;
-    DBuf<uint64_t> codes;
-    DBuf<uint32_t> acgt;
+    DBuf<uint32_t> records;
     DBuf<int32_t> workspace;
     DBuf<char> mate1;
     DBuf<int32_t> unit_begin, unit_end, unit_count;
@@ -126,7 +125,7 @@ struct skm_mapper {
     bool want_stats = false;
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
     unsigned long long stats_total[48] = {0};
-    int vote[8] = {32, 48, 32, 32, 32, 32, 0, 0};   // quorum per action (start, lookup, merge, left, right, emit)
+    int vote[8] = {1, 1, 1, 1, 1, 1, 0, 0};   // quorum per action (start, lookup, merge, left, right, emit)
 };
 
 struct skm_quant {
@@ -208,6 +207,38 @@ extern "C" int skm_device_synchronize(int device)
     return SKM_OK;
 }
 
+// Diagnostic: random 16-byte gathers over a zero-filled table of `table_bytes`
+// (power of two).  chain=0: independent gathers (throughput); chain=1: each
+// address depends on the previous slot (latency under load).
+extern "C" int skm_device_gather_ceiling(int device, int64_t table_bytes, int blocks, int per_lane,
+                                         int chain, double *gathers_per_second)
+{
+    if (!gathers_per_second || table_bytes < 4096 || (table_bytes & (table_bytes - 1)) || blocks < 1
+            || per_lane < 4)
+        return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(set_device(device));
+    void *table = nullptr;
+    unsigned long long *sink = nullptr;
+    HIP_TRY(hipMalloc(&table, (size_t)table_bytes));
+    HIP_TRY(hipMalloc((void **)&sink, 8));
+    HIP_TRY(hipMemset(table, 0, (size_t)table_bytes));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    launch_gather_probe(table, (uint64_t)table_bytes / 16, blocks, per_lane, chain, sink, nullptr);   // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    launch_gather_probe(table, (uint64_t)table_bytes / 16, blocks, per_lane, chain, sink, nullptr);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *gathers_per_second = (double)blocks * 256.0 * per_lane / (ms * 1e-3);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIP_TRY(hipFree(table));
+    HIP_TRY(hipFree(sink));
+    return SKM_OK;
+}
+
 // -------------------------------------------------------------------- index
 extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *contigs,
                                 int64_t n_contigs, const char *sequences, int64_t n_bases,
@@ -218,7 +249,8 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
         return fail(SKM_ERR_ARG, "NULL array");
     if (n_slots <= 0 || (n_slots & (n_slots - 1)) || n_slots > (1LL << 31))
         return fail(SKM_ERR_ARG, "k-mer table size %lld is not a power of two <= 2^31", (long long)n_slots);
-    if (n_contigs <= 0 || n_bases < ALIGN_LENGTH || n_targets < 0 || n_bases >= (1LL << 31))
+    if (n_contigs <= 0 || n_bases < ALIGN_LENGTH || n_targets < 0 || n_bases >= (1LL << 31)
+            || n_targets >= (1LL << 31) || n_contigs >= (1LL << 31))
         return fail(SKM_ERR_ARG, "bad index sizes");
     int n_dev = 0;
     SKM_TRY(skm_device_count(&n_dev));
@@ -255,12 +287,15 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     const int64_t n_words = (n_bases + 31) / 32 + 1;
     char *d_ascii = nullptr;
     HIP_TRY(hipMalloc(&ix->kmers, (size_t)n_slots * sizeof(IndexEntry)));
-    HIP_TRY(hipMalloc(&ix->contigs, (size_t)n_contigs * sizeof(ContigEntry)));
+    HIP_TRY(hipMalloc(&ix->contigs, (size_t)n_contigs * sizeof(DevContig)));
     HIP_TRY(hipMalloc(&ix->targets, (size_t)std::max<int64_t>(n_targets, 1) * sizeof(Coord)));
     HIP_TRY(hipMalloc(&ix->seq2, (size_t)n_words * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&d_ascii, (size_t)n_bases));
     HIP_TRY(hipMemcpy(ix->kmers, kmers, (size_t)n_slots * sizeof(IndexEntry), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ix->contigs, contigs, (size_t)n_contigs * sizeof(ContigEntry), hipMemcpyHostToDevice));
+    void *d_contigs48 = nullptr;
+    HIP_TRY(hipMalloc(&d_contigs48, (size_t)n_contigs * sizeof(ContigEntry)));
+    HIP_TRY(hipMemcpy(d_contigs48, contigs, (size_t)n_contigs * sizeof(ContigEntry), hipMemcpyHostToDevice));
+    launch_pack_contigs(d_contigs48, n_contigs, ix->contigs, nullptr);
     if (n_targets)
         HIP_TRY(hipMemcpy(ix->targets, targets, (size_t)n_targets * sizeof(Coord), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_ascii, sequences, (size_t)n_bases, hipMemcpyHostToDevice));
@@ -268,17 +303,18 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(d_ascii));
+    HIP_TRY(hipFree(d_contigs48));
     ix->n_slots = n_slots;
     ix->d.kmers = (const IndexEntry *)ix->kmers;
     ix->d.slot_mask = (uint32_t)(n_slots - 1);
-    ix->d.contigs = (const ContigEntry *)ix->contigs;
+    ix->d.contigs = (const DevContig *)ix->contigs;
     ix->d.n_contigs = n_contigs;
     ix->d.seq2 = (const uint64_t *)ix->seq2;
     ix->d.n_bases = n_bases;
     ix->d.targets = (const Coord *)ix->targets;
     ix->d.n_targets = n_targets;
     ix->d.max_target_count = (int32_t)std::max<int64_t>(max_tc, 1);
-    ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(ContigEntry)
+    ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(DevContig)
                 + n_targets * (int64_t)sizeof(Coord) + n_words * 8;
     *out = ix;
     return SKM_OK;
@@ -424,8 +460,8 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     m->last_ids = 0;
     if (n_units == 0) return SKM_OK;
 
-    SKM_TRY(m->codes.ensure((size_t)n_reads * words + 2));
-    SKM_TRY(m->acgt.ensure((size_t)n_reads * words + 2));
+    const int record_words = ((3 * words + 1 + 15) / 16) * 16;      // 64-byte records
+    SKM_TRY(m->records.ensure((size_t)n_reads * record_words + 16));
     SKM_TRY(m->unit_begin.ensure(n_units));
     SKM_TRY(m->unit_end.ensure(n_units));
     SKM_TRY(m->unit_count.ensure(n_units));
@@ -452,11 +488,10 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * 4 * 2048 + 4096));
 
     MapBatch b{};
-    b.codes = m->codes.p;
-    b.acgt = m->acgt.p;
-    b.offsets = d_offsets;
+    b.records = m->records.p;
     b.n_units = n_units;
     b.words_per_read = words;
+    b.record_words = record_words;
     b.paired = paired;
     b.workspace = m->workspace.p;
     b.mate1 = m->mate1.p;
@@ -472,7 +507,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     for (int i = 0; i < 8; ++i) b.vote[i] = m->vote[i];
 
     HIP_TRY(hipEventRecord(m->ev[0], m->stream));
-    launch_pack_reads(d_bases, d_offsets, n_reads, words, m->codes.p, m->acgt.p, m->stream);
+    launch_pack_reads(d_bases, d_offsets, n_reads, words, record_words, m->records.p, m->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev[1], m->stream));
     unsigned long long ids = 0;
@@ -581,8 +616,8 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     (void)hipStreamSynchronize(m->stream);
     m->slots.release(); m->arena_len.release(); m->arena.release(); m->class_list.release();
     m->counters.release();
-    m->error.release(); m->bases.release(); m->offsets.release(); m->codes.release();
-    m->acgt.release(); m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();
+    m->error.release(); m->bases.release(); m->offsets.release(); m->records.release();
+    m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();
     m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
     m->unit_slot.release(); m->unit_claim.release(); m->claim_scan.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);

@@ -26,14 +26,24 @@ struct ContigEntry {                                             // _common.pxd:
     int64_t target_offset, target_length;
 };
 
-// Index as it lives in HBM.  kmers/contigs/targets keep the reference's array
-// layout; the pooled contig bases are re-packed to 2 bits (32 bases per u64,
-// first base in the top bits) because the mapper only ever needs 8-base
-// windows of them.
+// Contig record as the kernels read it: the 48-byte reference row re-packed
+// at upload to 32 bytes (two per 64-byte sector, never straddling one).  The
+// mapper runs at the chip's random sector-request ceiling, so what counts is
+// how many sectors a contig visit touches.
+struct alignas(32) DevContig {
+    int32_t offset, length;            // into the pooled bases
+    int32_t target_offset, target_length;
+    uint64_t first_kmer, last_kmer;
+};
+
+// Index as it lives in HBM.  kmers/targets keep the reference's array layout;
+// contigs are re-packed (above) and the pooled contig bases go to 2 bits (32
+// bases per u64, first base in the top bits) because the mapper only ever
+// needs 8-base windows of them.
 struct DevIndex {
     const IndexEntry *kmers;
     uint32_t slot_mask;
-    const ContigEntry *contigs;
+    const DevContig *contigs;
     int64_t n_contigs;
     const uint64_t *seq2;      // 2-bit packed pooled bases, one zero pad word
     int64_t n_bases;
@@ -100,31 +110,32 @@ struct LaneStats {
 };
 
 // KMerIndex.map_kmer, _common.pyx:54-97.  Home slot = hash(min(kmer, rc)) &
-// (size-1); linear probe with wrap-around; empty slot ends the probe.  Four
+// (size-1); linear probe with wrap-around; empty slot ends the probe.  PROBE
 // consecutive slots are fetched per round trip (independent 16-byte loads) and
-// then examined in probe order, so a lane's probe chain costs ceil(P/4) memory
-// latencies instead of P; the slots examined -- and the result -- are the
-// reference's.
+// then examined in probe order: a chunk of 64 lookups waits for its slowest
+// lane, whose chain costs ceil(P/PROBE) memory latencies instead of P.  The
+// slots examined -- and the result -- are the reference's.
+constexpr int PROBE = 4;
 template <bool STATS>
 __device__ __forceinline__ Coord map_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
 {
     const uint64_t rc = kmer_revcomp(kmer);
     uint32_t slot = kmer_hash(kmer < rc ? kmer : rc) & ix.slot_mask;
     if (STATS) st->lookups++;
-    for (uint64_t n = 0; n <= ix.slot_mask; n += 4) {
-        uint4 raw[4];
+    for (uint64_t n = 0; n <= ix.slot_mask; n += PROBE) {
+        uint4 raw[PROBE];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < PROBE; ++j)
             raw[j] = *reinterpret_cast<const uint4 *>(&ix.kmers[(slot + j) & ix.slot_mask]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PROBE; ++j) {
             const uint64_t stored = ((uint64_t)raw[j].y << 32) | raw[j].x;
             if (STATS) st->slots++;
             if (stored == KMER_INVALID) return invalid_coord();
             if (stored == kmer) return Coord{(int32_t)raw[j].z, (int32_t)raw[j].w};
             if (stored == rc) return Coord{~(int32_t)raw[j].z, (int32_t)raw[j].w};
         }
-        slot = (slot + 4) & ix.slot_mask;
+        slot = (slot + PROBE) & ix.slot_mask;
     }
     return invalid_coord();
 }
@@ -157,7 +168,7 @@ template <bool STATS>
 __device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, bool leading, LaneStats *st)
 {
     int32_t index = c.entry < 0 ? ~c.entry : c.entry;
-    int64_t offset = ix.contigs[index].offset + c.offset;
+    int64_t offset = (int64_t)ix.contigs[index].offset + c.offset;
     if (STATS) { st->contig_reads++; st->seq_fetches++; }
     if (c.entry >= 0) offset += leading ? ALIGN_LENGTH : K;
     else offset += leading ? K : ALIGN_LENGTH;
@@ -184,11 +195,20 @@ __device__ __forceinline__ uint64_t tail_kmer(const DevIndex &ix, Coord c, LaneS
 // ACGT/acgt encode as 0, _kmer.pxd:253-273) plus one bit per base that says
 // "is upper-case ACGT" -- the only property _match_base needs
 // (_mapper.pyx:500-501).
+// One record per read, 64-byte aligned: W code words (u64), W mask words (u32,
+// 32 bases per word, first base in the top bit), then the read length (u32).
 struct ReadView {
     const uint64_t *codes;
-    const uint32_t *acgt;     // 32 bases per word, first base in the top bit
+    const uint32_t *acgt;
     int len;
 };
+__device__ __forceinline__ ReadView read_view(const uint32_t *records, int record_words, int words_per_read,
+                                              int64_t r)
+{
+    const uint32_t *rec = records + r * (int64_t)record_words;
+    return ReadView{reinterpret_cast<const uint64_t *>(rec), rec + 2 * words_per_read,
+                    (int)rec[3 * words_per_read]};
+}
 
 __device__ __forceinline__ uint64_t read_kmer(const ReadView &r, int p)      // _kmer.pxd:46-68
 {

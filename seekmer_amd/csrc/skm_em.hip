@@ -346,3 +346,40 @@ void launch_pack_sequences(const char *bases, int64_t n_bases, uint64_t *seq2, i
 }
 
 }  // namespace skm
+
+// ------------------------------------------------------------ diagnostics
+// Random 16-byte gathers over a table of `n_slots` slots: the ceiling the
+// index probes of the mapper can be priced against.  `chain` = 1:
+// every lane's next address depends on the slot it just read (latency under
+// load); `chain` = 0: `per_lane` independent gathers (throughput).
+namespace skm {
+__global__ void __launch_bounds__(256)
+gather_probe_kernel(const uint4 *__restrict__ table, uint64_t slot_mask, int per_lane, int chain,
+                    unsigned long long *sink)
+{
+    uint64_t x = mix64(blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    unsigned long long acc = 0;
+    if (chain) {
+        for (int i = 0; i < per_lane; ++i) {
+            const uint4 v = table[x & slot_mask];
+            acc += v.x;
+            x = mix64(x + v.y + i);
+        }
+    } else {
+        for (int i = 0; i < per_lane; i += 4) {
+            const uint64_t a = mix64(x + i), b2 = mix64(x + i + 1), c = mix64(x + i + 2), d = mix64(x + i + 3);
+            const uint4 v0 = table[a & slot_mask], v1 = table[b2 & slot_mask], v2 = table[c & slot_mask],
+                        v3 = table[d & slot_mask];
+            acc += v0.x + v1.x + v2.x + v3.x;
+        }
+    }
+    if (acc == 0x123456789ULL) *sink = acc;
+}
+
+void launch_gather_probe(const void *table, uint64_t n_slots, int blocks, int per_lane, int chain,
+                         unsigned long long *sink, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gather_probe_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4 *)table,
+                       n_slots - 1, per_lane, chain, sink);
+}
+}  // namespace skm

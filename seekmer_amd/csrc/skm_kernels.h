@@ -7,11 +7,10 @@ namespace skm {
 
 // One batch on its way through the mapper (all pointers are device memory).
 struct MapBatch {
-    const uint64_t *codes;        // [n_reads][words_per_read] packed 2-bit codes
-    const uint32_t *acgt;         // [n_reads][words_per_read] "is upper-case ACGT" bits
-    const int64_t *offsets;       // [n_reads + 1] byte offsets of the raw reads
+    const uint32_t *records;      // [n_reads][record_words]: codes (u64 x W), ACGT bits (u32 x W), length
     int64_t n_units;
-    int32_t words_per_read;
+    int32_t words_per_read;       // W
+    int32_t record_words;         // u32 words per record, a multiple of 16 (64 bytes)
     int32_t paired;
     int32_t *workspace;           // per-context mask extension words (slices > 64 targets)
     void *mate1;                  // per-context parking slot of the mate-1 span and set (48 B)
@@ -30,11 +29,15 @@ struct MapBatch {
 };
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
-                       int words_per_read, uint64_t *codes, uint32_t *acgt, hipStream_t stream);
+                       int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
+void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream);
 void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bool stats,
                       hipStream_t stream);
 void launch_pack_sequences(const char *bases, int64_t n_bases, uint64_t *seq2, int64_t n_words,
                            hipStream_t stream);
+
+void launch_gather_probe(const void *table, uint64_t n_slots, int blocks, int per_lane, int chain,
+                         unsigned long long *sink, hipStream_t stream);
 
 // ---- equivalence-class table (skm_classes.hip)
 struct ClassSlot {                // 32 B

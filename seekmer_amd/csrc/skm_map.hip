@@ -37,8 +37,7 @@ __device__ __forceinline__ void pack_dword(uint32_t w, int first, int n, uint64_
 
 __global__ void __launch_bounds__(256)
 pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offsets,
-                  int64_t n_reads, int words_per_read,
-                  uint64_t *__restrict__ codes, uint32_t *__restrict__ acgt)
+                  int64_t n_reads, int words_per_read, int record_words, uint32_t *__restrict__ records)
 {
     const int64_t total = n_reads * (int64_t)words_per_read;
     const int64_t end_of_bases = offsets[n_reads];
@@ -65,8 +64,28 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
                 for (int i = 0; i < n; ++i) pack_dword(bases[at + i], i, i + 1, c, m);
             }
         }
-        codes[g] = c;
-        acgt[g] = m;
+        uint32_t *rec = records + r * (int64_t)record_words;
+        reinterpret_cast<uint64_t *>(rec)[w] = c;
+        rec[2 * words_per_read + w] = m;
+        if (w == 0) rec[3 * words_per_read] = (uint32_t)len;
+    }
+}
+
+// reference contig rows (48 B) -> DevContig (32 B)
+__global__ void __launch_bounds__(256)
+pack_contigs_kernel(const ContigEntry *__restrict__ in, int64_t n, DevContig *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const ContigEntry c = in[i];
+        DevContig d;
+        d.offset = (int32_t)c.offset;
+        d.length = (int32_t)c.length;
+        d.target_offset = (int32_t)c.target_offset;
+        d.target_length = (int32_t)c.target_length;
+        d.first_kmer = c.first_kmer;
+        d.last_kmer = c.last_kmer;
+        out[i] = d;
     }
 }
 
@@ -475,17 +494,11 @@ map_units_kernel(DevIndex ix, MapBatch b)
             uint64_t *const ext2 = ext1 + 2 * (size_t)ext_words;
             TSet set{c_tstart[c], c_tlen[c] >> 1, (c_tlen[c] & 1) != 0,
                      ((uint64_t)c_mask_hi[c] << 32) | c_mask_lo[c], mate ? ext2 : ext1, ext_words};
-            ReadView rv;
-            {
-                const int64_t r = b.paired ? 2 * u + mate : u;
-                rv.codes = b.codes + r * b.words_per_read;
-                rv.acgt = b.acgt + r * b.words_per_read;
-                rv.len = c_len[c];
-            }
+            ReadView rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u + mate : u);
+            rv.len = c_len[c];          // (kept with the context: saves touching the record)
 
             if (valid && action == A_START) {
-                const int64_t r = b.paired ? 2 * u : u;
-                rv.len = (int)(b.offsets[r + 1] - b.offsets[r]);
+                rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u : u);
                 mate = 0;
                 attempt = 0;
                 span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
@@ -730,10 +743,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     set.word0 = 0;
                     mate = 1;
                     attempt = 0;
-                    const int64_t r = 2 * u + 1;
-                    rv.codes = b.codes + r * b.words_per_read;
-                    rv.acgt = b.acgt + r * b.words_per_read;
-                    rv.len = (int)(b.offsets[r + 1] - b.offsets[r]);
+                    rv = read_view(b.records, b.record_words, b.words_per_read, 2 * u + 1);
                     span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
                     if (STATS) { read_bases += rv.len; n_reads++; }
                     if (rv.len >= K) {
@@ -811,15 +821,23 @@ map_units_kernel(DevIndex ix, MapBatch b)
     }
 }
 
+void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream)
+{
+    int64_t blocks = (n_contigs + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_contigs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       (const ContigEntry *)contigs48, n_contigs, (DevContig *)contigs32);
+}
+
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
-                       int words_per_read, uint64_t *codes, uint32_t *acgt, hipStream_t stream)
+                       int words_per_read, int record_words, uint32_t *records, hipStream_t stream)
 {
     const int64_t total = n_reads * (int64_t)words_per_read;
     if (total == 0) return;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       bases, offsets, n_reads, words_per_read, codes, acgt);
+                       bases, offsets, n_reads, words_per_read, record_words, records);
 }
 
 void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bool stats,
