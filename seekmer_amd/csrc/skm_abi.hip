@@ -135,7 +135,7 @@ struct skm_quant {
     std::mutex mu;
     int64_t n_tx = 0, n_classes = 0, n_ids = 0, n_rows = 0;
     DBuf<int64_t> cls_offset, row_start, tx_row;
-    DBuf<int32_t> ids, tx_cls, row_tx;
+    DBuf<int32_t> ids, tx_cls, row_tx, perm;      // perm[k] = caller's index of internal class k
     DBuf<double> cls_count, cls_count_saved, inner, row_sum;
     DBuf<double> eff_len, x0, x1, acc, part_max;
     DBuf<unsigned int> part_flags;
@@ -915,6 +915,7 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     SKM_TRY(q->cls_count.ensure(C));
     SKM_TRY(q->inner.ensure(C));
     SKM_TRY(q->ids.ensure(M));
+    SKM_TRY(q->perm.ensure(C));
     SKM_TRY(q->tx_cls.ensure(M));
     SKM_TRY(q->tx_row.ensure(T + 1));
     SKM_TRY(q->row_start.ensure(R + 1));
@@ -950,6 +951,8 @@ QuantBuild quant_build_view(skm_quant *q)
 int quant_transpose(skm_quant *q)
 {
     QuantBuild b = quant_build_view(q);
+    if (quant_localize(b, q->perm.p, q->stream) != 0)
+        return fail(SKM_ERR_HIP, "ordering the classes for locality failed: %s", hipGetErrorString(hipGetLastError()));
     const int64_t rows = quant_build_transpose(b, q->stream);
     if (rows < 0) return fail(SKM_ERR_HIP, "building the transcript-major class view failed (%lld): %s",
                               (long long)rows, hipGetErrorString(hipGetLastError()));
@@ -1146,7 +1149,7 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     (void)hipSetDevice(q->device);
     (void)hipStreamSynchronize(q->stream);
     q->cls_offset.release(); q->row_start.release(); q->tx_row.release(); q->ids.release();
-    q->tx_cls.release(); q->row_tx.release(); q->cls_count.release(); q->cls_count_saved.release();
+    q->tx_cls.release(); q->row_tx.release(); q->perm.release(); q->cls_count.release(); q->cls_count_saved.release();
     q->inner.release(); q->row_sum.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
     q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
     q->cum.release(); q->draw.release();
@@ -1178,8 +1181,14 @@ extern "C" int skm_quant_set_counts(skm_quant *q, const double *class_counts)
     SKM_TRY(set_device(q->device));
     double total = 0;
     for (int64_t c = 0; c < q->n_classes; ++c) total += class_counts[c];
-    if (q->n_classes)
-        HIP_TRY(hipMemcpy(q->cls_count.p, class_counts, q->n_classes * 8, hipMemcpyHostToDevice));
+    if (q->n_classes) {
+        // caller's class order -> internal (locality) order
+        SKM_TRY(q->cls_count_saved.ensure(q->n_classes));
+        HIP_TRY(hipMemcpyAsync(q->cls_count_saved.p, class_counts, q->n_classes * 8, hipMemcpyHostToDevice, q->stream));
+        launch_permute_f64(q->cls_count_saved.p, q->perm.p, q->n_classes, q->cls_count.p, false, q->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(q->stream));
+    }
     q->n_total = total;
     return SKM_OK;
 }
@@ -1216,8 +1225,13 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
         launch_u64_to_double(q->draw.p, C, q->cls_count.p, q->stream);
         HIP_TRY(hipGetLastError());
         if (counts_out) {
-            static_assert(sizeof(unsigned long long) == sizeof(int64_t), "");
-            HIP_TRY(hipMemcpyAsync(counts_out + b * C, q->draw.p, C * 8, hipMemcpyDeviceToHost, q->stream));
+            // internal (locality) class order -> caller's order; the counts fit a double exactly
+            SKM_TRY(q->inner.ensure(C));
+            launch_permute_f64(q->cls_count.p, q->perm.p, C, q->inner.p, true, q->stream);
+            std::vector<double> as_double(C);
+            HIP_TRY(hipMemcpyAsync(as_double.data(), q->inner.p, C * 8, hipMemcpyDeviceToHost, q->stream));
+            HIP_TRY(hipStreamSynchronize(q->stream));
+            for (int64_t c = 0; c < C; ++c) counts_out[b * C + c] = (int64_t)as_double[c];
         }
         HIP_TRY(hipMemcpyAsync(q->x0.p, x0, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
         q->n_total = (double)n_draws;

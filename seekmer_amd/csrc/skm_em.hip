@@ -4,7 +4,7 @@
 // (effective_lengths) and the scipy draw of infer.py:108-111.
 //
 // One EM step is a two-sided gather over two CSR views of the same
-// (class, transcript) pairs, three launches on one stream and no
+// (class, transcript) pairs, four launches on one stream and no
 // floating-point atomics, so every step is bitwise reproducible:
 //   em_inner     -- one lane per class: S_c = sum of x over the tuple in tuple
 //                   order (as numpy.bincount accumulates it), inner_c = S_c /
@@ -12,17 +12,18 @@
 //   em_rows      -- 8 lanes per row (a run of <= 512 classes of ONE transcript):
 //                   sum of x_t / inner_c over the run          (infer.py:157)
 //   em_finalize  -- one lane per transcript: x'_t = (sum of its rows) / l_t /
-//                   n, NaN -> 0, relative change against x_t; block partials;
-//                   the last block to finish evaluates the reference's stopping
-//                   rule (infer.py:160) and latches `done`, after which every
-//                   later launch is a no-op -- the host enqueues steps in
-//                   chunks and still stops at exactly the reference's count.
+//                   n, NaN -> 0, relative change against x_t; block partials
+//   em_decide    -- one block: reduces the partials, evaluates the reference's
+//                   stopping rule (infer.py:160) and latches `done`, after
+//                   which every later launch is a no-op -- the host enqueues
+//                   steps in chunks and still stops at exactly the reference's
+//                   iteration count.
 // All three are gather/stream kernels bound by HBM/L2 bandwidth: no MFMA.
 #include "skm_kernels.h"
 
 namespace skm {
 
-enum { CTL_DONE = 0, CTL_ITERS = 1, CTL_TICKET = 2, CTL_UNDEFINED = 3 };
+enum { CTL_DONE = 0, CTL_ITERS = 1, CTL_UNDEFINED = 3 };
 
 __global__ void __launch_bounds__(256)
 em_inner_kernel(EmProblem p, int parity)
@@ -91,7 +92,6 @@ em_finalize_kernel(EmProblem p, int parity)
     if (p.ctl[CTL_DONE]) return;
     __shared__ double s_max[4];
     __shared__ unsigned int s_flags[4];
-    __shared__ bool s_last;
     const double *__restrict__ x_old = p.x[parity];
     double *__restrict__ x_new = p.x[parity ^ 1];
     double local_max = 0.0;
@@ -127,37 +127,37 @@ em_finalize_kernel(EmProblem p, int parity)
         double m = s_max[0];
         unsigned int f = s_flags[0];
         for (int w = 1; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
-        __hip_atomic_store(&p.part_max[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.part_flags[blockIdx.x], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the partials are agent-scope (write-through, sc1) stores: drained before the
-        // ticket they need no L2 write-back fence, and the last block reads them with
-        // agent-scope (sc1) loads (MI355X_MICROARCH "Valid forms")
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long ticket = atomicAdd(&p.ctl[CTL_TICKET], 1ULL);
-        s_last = ticket == gridDim.x - 1;
+        p.part_max[blockIdx.x] = m;             // reduced by em_decide_kernel (next launch)
+        p.part_flags[blockIdx.x] = f;
     }
-    __syncthreads();
-    if (!s_last) return;
-    // last block: every other block's partials are published
+}
+
+// One block: reduce the per-block partials of the finalize launch before it and
+// apply the reference's stopping rule (infer.py:160).  A launch boundary is
+// cheaper here than hundreds of tickets on one device-scope counter.
+__global__ void __launch_bounds__(256)
+em_decide_kernel(EmProblem p, int n_parts)
+{
+    if (p.ctl[CTL_DONE]) return;
+    __shared__ double s_max[4];
+    __shared__ unsigned int s_flags[4];
     double m = 0.0;
     unsigned int f = 0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
-        const double o = __hip_atomic_load(&p.part_max[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int b = threadIdx.x; b < n_parts; b += blockDim.x) {
+        const double o = p.part_max[b];
         m = o > m ? o : m;
-        f |= __hip_atomic_load(&p.part_flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f |= p.part_flags[b];
     }
     for (int d = 32; d > 0; d >>= 1) {
         const double o = __shfl_xor(m, d, 64);
         m = o > m ? o : m;
         f |= __shfl_xor(f, d, 64);
     }
-    __syncthreads();
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_max[wave] = m; s_flags[wave] = f; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
-        m = s_max[0] > m ? s_max[0] : m;
-        f |= s_flags[0];
+        for (int w = 0; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
         const unsigned long long iters = p.ctl[CTL_ITERS] + 1;
         bool done;
         if (p.fixed_iters > 0) {
@@ -170,7 +170,6 @@ em_finalize_kernel(EmProblem p, int parity)
             if (p.max_iters > 0 && (int64_t)iters >= p.max_iters) done = true;
         }
         p.ctl[CTL_ITERS] = iters;
-        p.ctl[CTL_TICKET] = 0;
         p.ctl[CTL_DONE] = done ? 1ULL : 0ULL;
     }
 }
@@ -234,6 +233,16 @@ multinomial_kernel(const unsigned long long *__restrict__ cum, int64_t n_classes
             if (cum[mid] > r) hi = mid; else lo = mid + 1;
         }
         atomicAdd(&counts[lo], 1ULL);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+permute_f64_kernel(const double *__restrict__ x, const int32_t *__restrict__ perm, int64_t n,
+                   double *__restrict__ y, bool scatter)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (scatter) y[perm[i]] = x[i]; else y[i] = x[perm[i]];
     }
 }
 
@@ -308,6 +317,7 @@ void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream
         hipLaunchKernelGGL(em_finalize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, parity);
     else
         hipLaunchKernelGGL(em_finalize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, parity);
+    hipLaunchKernelGGL(em_decide_kernel, dim3(1), dim3(256), 0, stream, p, (int)blocks);
 }
 
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
@@ -324,6 +334,13 @@ void launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_
     if (n_draws <= 0 || n_classes <= 0) return;
     hipLaunchKernelGGL(multinomial_kernel, dim3(grid_for(n_draws)), dim3(256), 0, stream, cum,
                        n_classes, n_draws, seed, stream_id, counts);
+}
+
+void launch_permute_f64(const double *x, const int32_t *perm, int64_t n, double *y, bool scatter,
+                        hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(permute_f64_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, perm, n, y, scatter);
 }
 
 void launch_u64_to_double(const unsigned long long *in, int64_t n, double *out, hipStream_t stream)

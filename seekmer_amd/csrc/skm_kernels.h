@@ -134,6 +134,11 @@ struct QuantBuild {
 // classes taken from a mapper's table, ordered by first-seen unit (the reference's class order)
 int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids, QuantBuild &q,
                            hipStream_t stream);
+// stable reorder of the classes by smallest transcript id (gather locality); perm[k] = caller index
+int quant_localize(QuantBuild &q, int32_t *perm, hipStream_t stream);
+// y[k] = x[perm[k]] (gather) or y[perm[k]] = x[k] (scatter), n doubles / u64
+void launch_permute_f64(const double *x, const int32_t *perm, int64_t n, double *y, bool scatter,
+                        hipStream_t stream);
 // builds tx_cls / tx_row / row_* from cls_offset + ids; returns the number of rows (or < 0)
 int64_t quant_build_transpose(QuantBuild &q, hipStream_t stream);
 int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids);

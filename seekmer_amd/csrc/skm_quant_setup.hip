@@ -124,6 +124,33 @@ row_fill_kernel(const int64_t *tx_offset, const int64_t *tx_row, int64_t n_tx, i
     }
 }
 
+// locality key of a class: its smallest transcript id
+__global__ void __launch_bounds__(256)
+class_min_id_kernel(const int64_t *cls_offset, const int32_t *ids, int64_t n_classes, uint32_t *key,
+                    int64_t *len)
+{
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_classes;
+         c += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t m = 0xffffffffu;
+        for (int64_t j = cls_offset[c]; j < cls_offset[c + 1]; ++j) m = min(m, (uint32_t)ids[j]);
+        key[c] = m;
+        len[c] = cls_offset[c + 1] - cls_offset[c];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+copy_tuples_by_offset_kernel(const int32_t *perm, int64_t n, const int64_t *src_offset, const int32_t *src,
+                             const int64_t *dst_offset, int32_t *dst)
+{
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t from = src_offset[perm[k]];
+        const int64_t to = dst_offset[k];
+        const int64_t len = dst_offset[k + 1] - to;
+        for (int64_t j = 0; j < len; ++j) dst[to + j] = src[from + j];
+    }
+}
+
 inline unsigned blocks_for(int64_t n)
 {
     int64_t b = (n + 255) / 256;
@@ -208,6 +235,48 @@ int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids
     QB_TRY(hipGetLastError());
     QB_TRY(hipStreamSynchronize(stream));
     (void)n_ids;
+    return 0;
+}
+
+// Reorder the classes (stably) by their smallest transcript id.  The EM result
+// does not depend on class order beyond floating-point association, but the
+// transcript-major pass gathers inner[c] over a transcript's classes, and
+// classes that share transcripts then sit in neighbouring cache sectors
+// instead of being spread over the whole first-seen order.  perm[k] = index of
+// internal class k in the caller's order.
+int quant_localize(QuantBuild &q, int32_t *perm, hipStream_t stream)
+{
+    const int64_t C = q.n_classes, M = q.n_ids;
+    if (C == 0) return 0;
+    if (C >= (1LL << 31) || M >= (1LL << 31)) return -2;
+    Tmp<uint32_t> key, key_sorted;
+    Tmp<int32_t> iota, ids_copy;
+    Tmp<int64_t> len, len_sorted, old_offset;
+    Tmp<double> count_copy;
+    QB_TRY(key.alloc(C)); QB_TRY(key_sorted.alloc(C)); QB_TRY(iota.alloc(C)); QB_TRY(ids_copy.alloc(M));
+    QB_TRY(len.alloc(C)); QB_TRY(len_sorted.alloc(C)); QB_TRY(old_offset.alloc(C + 1)); QB_TRY(count_copy.alloc(C));
+    hipLaunchKernelGGL(class_min_id_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, q.cls_offset, q.ids, C,
+                       key.p, len.p);
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, iota.p, C);
+    int end_bit = 1;
+    while ((1LL << end_bit) < q.n_tx && end_bit < 32) ++end_bit;
+    size_t bytes = 0;
+    QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key.p, key_sorted.p, iota.p, perm, (int)C, 0,
+                                             end_bit, stream));
+    Tmp<char> tmp;
+    QB_TRY(tmp.alloc(bytes));
+    QB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, key.p, key_sorted.p, iota.p, perm, (int)C, 0,
+                                             end_bit, stream));
+    QB_TRY(hipMemcpyAsync(old_offset.p, q.cls_offset, (C + 1) * 8, hipMemcpyDeviceToDevice, stream));
+    QB_TRY(hipMemcpyAsync(ids_copy.p, q.ids, M * 4, hipMemcpyDeviceToDevice, stream));
+    QB_TRY(hipMemcpyAsync(count_copy.p, q.cls_count, C * 8, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, perm, C, len.p,
+                       count_copy.p, len_sorted.p, q.cls_count);
+    if (exclusive_scan_with_total(len_sorted.p, q.cls_offset, C, stream)) return -1;
+    hipLaunchKernelGGL(copy_tuples_by_offset_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, perm, C,
+                       old_offset.p, ids_copy.p, q.cls_offset, q.ids);
+    QB_TRY(hipGetLastError());
+    QB_TRY(hipStreamSynchronize(stream));
     return 0;
 }
 
