@@ -188,6 +188,17 @@ def main():
                    + 4 * st['tuple_ids'])
     achieved = algorithmic / map_ns if map_ns else 0.0          # bytes/ns = GB/s
     sizes = result.sizes()
+    # HBM traffic of the same launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, rocprofv3,
+    # separate --pmc runs, profiles/r01_c_pmc_map.json); only quoted for the workload it was taken on
+    traffic, miss_rate = None, None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_c_pmc_map.json')) as f:
+            pmc = json.load(f)
+        if args.genes == 20000 and n_units == 10_000_000 and args.read_len == 100:
+            traffic = pmc['derived']['hbm_traffic_bytes']
+            miss_rate = pmc['per_launch']['TCC_MISS_sum'] / (map_ns * 1e-9)
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         line = {
@@ -220,8 +231,11 @@ def main():
                 'kernel': 'map_units_kernel', 'bound': 'hbm',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': traffic,
                 'algorithmic_bytes_per_launch': algorithmic,
+                # the probes are dependent random 16-B reads: the relevant ceiling is the chip's
+                # random-gather rate (52 G/s over a 2 GiB table, profiles/r01_gather_ceiling.log)
+                'l2_miss_rate_vs_random_gather_ceiling': (miss_rate / 52.3e9) if miss_rate else None,
                 'bytes_per_pair': algorithmic / n_units,
                 'launch_ms': map_ns * 1e-6,
             },
