@@ -21,18 +21,37 @@ namespace skm {
 // index space is [n_reads][words_per_read].
 struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };
 
+// one base (tail of the batch only)
+__device__ __forceinline__ void pack_byte(uint32_t ch, int i, uint64_t &codes, uint32_t &acgt)
+{
+    codes |= (uint64_t)two_bit_encode(ch) << (62 - 2 * i);
+    const bool up = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+    acgt |= (uint32_t)up << (31 - i);
+}
+
+// four bases at once (bases `first` .. `first`+3 of the word, `first` a multiple
+// of 4; only those below `n` count).  SWAR: (c >> 1) & 3 is 0,1,2,3 for A,C,T,G
+// in either case, a byte permute looks the letter up again to tell ACGT from
+// everything else, and two multiplies gather the 2-bit codes / flag bits.
 __device__ __forceinline__ void pack_dword(uint32_t w, int first, int n, uint64_t &codes, uint32_t &acgt)
 {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = first + k;
-        if (i < n) {
-            const uint32_t ch = (w >> (8 * k)) & 0xffu;
-            codes |= (uint64_t)two_bit_encode(ch) << (62 - 2 * i);
-            const bool up = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-            acgt |= (uint32_t)up << (31 - i);
-        }
-    }
+    const int cnt = n - first;
+    if (cnt <= 0) return;
+    const uint32_t keep = cnt >= 4 ? 0xffffffffu : ((1u << (8 * cnt)) - 1u);
+    const uint32_t up = w & 0xDFDFDFDFu;                              // fold case
+    const uint32_t idx = (up >> 1) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, idx);   // 'A','C','T','G' by idx
+    const uint32_t t = up ^ expect;
+    uint32_t valid = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 where ACGT/acgt
+    valid &= keep;
+    uint32_t code = idx ^ ((idx >> 1) & 0x01010101u);                 // A0 C1 G2 T3 (_kmer.pxd:253-273)
+    code &= (valid >> 7) * 3u;                                        // anything else encodes as 0
+    const uint32_t upper = valid & ~((w << 2) & 0x80808080u);         // and is upper case
+    const uint32_t code_byte = (code * 0x40100401u) >> 24;            // first base in the top bits
+    const uint32_t flag_nibble = (((upper >> 7) * 0x08040201u) >> 24) & 0xFu;
+    const int d = first >> 2;
+    codes |= (uint64_t)code_byte << (56 - 8 * d);
+    acgt |= flag_nibble << (28 - 4 * d);
 }
 
 __global__ void __launch_bounds__(256)
@@ -43,7 +62,9 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
     const int64_t end_of_bases = offsets[n_reads];
     for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = g / words_per_read;
+        // (32-bit division when the index fits: the 64-bit one is a long software routine)
+        const int64_t r = total <= 0xffffffffLL ? (int64_t)((uint32_t)g / (uint32_t)words_per_read)
+                                                : g / words_per_read;
         const int w = (int)(g - r * words_per_read);
         const int64_t begin = offsets[r];
         const int len = (int)(offsets[r + 1] - begin);
@@ -61,7 +82,7 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
 #pragma unroll
                 for (int d = 0; d < 4; ++d) pack_dword(hi.w[d], 16 + 4 * d, n, c, m);
             } else {                                   // last bytes of the batch: stay in bounds
-                for (int i = 0; i < n; ++i) pack_dword(bases[at + i], i, i + 1, c, m);
+                for (int i = 0; i < n; ++i) pack_byte(bases[at + i], i, c, m);
             }
         }
         uint32_t *rec = records + r * (int64_t)record_words;
