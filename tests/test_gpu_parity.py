@@ -354,3 +354,23 @@ def test_full_size_properties(oracle, native_libs):
     mapper.ReadMapper(index, single).map_batch(
         common.ReadBatch(2 * n_units, bases, offsets, False))
     assert single.fragment_length_counts.sum() == 2 * n_units  # every read counted
+
+
+@pytest.mark.parametrize('read_len,paired', [(150, False), (251, True), (33, True)])
+def test_other_read_lengths(oracle, native_libs, read_len, paired):
+    """BASELINE.json configs[3] shape (150 bp single-ended) and reads that need
+    more than one 64-byte record / barely more than k bases."""
+    from seekmer_amd import synth, index_builder
+    ids, pool, tx_offsets = synth.transcriptome(11, 120)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    oindex = oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                                lengths=np.diff(tx_offsets))
+    n_units = 20000
+    bases, offsets = synth.reads(11, pool, tx_offsets, 0, n_units, min(read_len, 299), paired)
+    if read_len != min(read_len, 299):
+        pytest.skip('generator limit')
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(oindex, bases, offsets, n_units, paired, fld)
+    result, units = _run_gpu(index, bases, offsets, n_units, paired)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
