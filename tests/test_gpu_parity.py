@@ -374,3 +374,62 @@ def test_other_read_lengths(oracle, native_libs, read_len, paired):
     result, units = _run_gpu(index, bases, offsets, n_units, paired)
     _compare_units(expected, units)
     _compare_tables(oracle, expected, fld, result)
+
+
+def test_module_surface(oracle, native_libs, chr21, chr21_oracle_index, pairs21, tmp_path):
+    """The reference's module API on the device-backed MapResult: map_reads with
+    worker threads and the Python feeders, Counter view, update(), clear(),
+    merge_fragment_lengths(), harmonic mean, map_multiple_samples."""
+    import collections
+    import pathlib
+    from conftest import GOLDEN
+    from seekmer_amd import common, mapper
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    paths = [pathlib.Path(GOLDEN) / '20_1.fastq', pathlib.Path(GOLDEN) / '20_2.fastq']
+
+    bases, offsets = oracle.pack_reads(pairs21)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, 21, True, fld)
+    want = collections.Counter(expected.tuples())
+
+    for jobs in (1, 3):
+        result = mapper.map_reads(index, common.feed_pair_ended_reads(*paths), job_count=jobs)
+        assert result.counter == want
+        np.testing.assert_array_equal(result.fragment_length_counts, fld)
+        assert abs(result.harmonic_mean_fragment_length - oracle.harmonic_mean_fragment_length(fld)) < 1e-9
+        summarized = result.summarize()
+        assert (summarized.aligned, summarized.unaligned, summarized.total) == (21, 0, 21)
+        assert summarized.class_map.dtype == np.int64 and summarized.class_map.shape[0] == 2
+        np.testing.assert_array_equal(result.effective_lengths,
+                                      oracle.effective_lengths(fld, chr21_oracle_index.lengths))
+
+    # update() with tuples (Counter.update semantics), then clear() keeps the histogram
+    result.update([b'x', b'y', b'z'], [(5, 6), (), (5, 6)])
+    counter = result.counter
+    assert counter[(5, 6)] == want.get((5, 6), 0) + 2 and counter[()] == 1
+    assert result.sizes()[3] == 24
+    result.merge_fragment_lengths(fld)
+    np.testing.assert_array_equal(result.fragment_length_counts, 2 * fld)
+    result.clear()
+    assert result.counter == collections.Counter()
+    np.testing.assert_array_equal(result.fragment_length_counts, 2 * fld)
+
+    # many threads hammering one handle: integer results are order independent
+    rng = np.random.default_rng(21)
+    reads = _adversarial_reads(chr21[1], rng, 8000, 80)
+    big_bases, big_offsets = oracle.pack_reads(reads)
+    big_fld = np.zeros(2000, dtype=np.int64)
+    big = oracle.map_batch(chr21_oracle_index, big_bases, big_offsets, 4000, True, big_fld)
+
+    def feeder():
+        for lo in range(0, 4000, 250):
+            yield common.ReadBatch(250, big_bases, np.ascontiguousarray(big_offsets[2 * lo:2 * lo + 501]), True)
+    threaded = mapper.map_reads(index, feeder(), job_count=6)
+    assert threaded.counter == collections.Counter(big.tuples())
+    np.testing.assert_array_equal(threaded.fragment_length_counts, big_fld)
+
+    samples = mapper.map_multiple_samples(
+        index, [common.feed_pair_ended_reads(*paths), common.feed_single_ended_reads(paths[0])], job_count=2)
+    assert samples[0].counter == want
+    single = oracle.map_batch(chr21_oracle_index, *oracle.pack_reads(pairs21[0::2]), 21, False)
+    assert samples[1].counter == collections.Counter(single.tuples())
