@@ -130,26 +130,43 @@ def main():
 
     state = {}
 
+    stage = {}
+    profile_stages = os.environ.get('SKM_BENCH_PROFILE') == '1'
+
+    def mark(name, t0):
+        if profile_stages:
+            _native.check(hip.skm_device_synchronize(device))
+            stage[name] = stage.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
     def step():
+        t = time.perf_counter()
         result.reset()
+        t = mark('reset', t)
         result.map_resident(d_bases, d_offsets, n_units, True, args.read_len)
+        t = mark('map_batch', t)
         fld = result.fragment_length_counts
         if world > 1:                      # MapResult.merge_fragment_lengths across ranks
             import torch
             t = torch.from_numpy(fld)
             dist.all_reduce(t)
         eff = result._effective_lengths(fld)
+        t = mark('fld+eff_len', t)
         quant = infer._QuantHandle.from_map_result(result, n_tx)
+        t = mark('quant_setup', t)
         try:
             if comm:
                 _native.check(hip.skm_quant_set_comm(quant.handle, comm))
             x = np.ones(n_tx, dtype='f8') / eff
             x /= x.sum()
             x, iters = quant.em(x, eff)
+            t = mark('em', t)
             state['em'] = quant.timing()
         finally:
             quant.close()
+        t = mark('quant_close', t)
         state['tpm'] = infer._tpm(x)
+        t = mark('tpm', t)
         state['iters'] = iters
 
     def barrier():
@@ -172,6 +189,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     t_after = result.timing()
+    if profile_stages and rank == 0:
+        log('stage ms per step: ' + ', '.join('%s %.2f' % (k, 1e3 * v / (args.steps + args.warmup))
+                                              for k, v in stage.items()))
 
     # ---------------- roofline of the dominant kernel (map_units_kernel)
     launches = t_after['batches'] - t_before['batches']

@@ -115,6 +115,8 @@ struct skm_mapper {
     DBuf<Coord> unit_anchor;
     DBuf<int64_t> unit_offset, unit_slot;
     DBuf<unsigned long long> unit_claim, claim_scan;
+    DBuf<char> scan_temp;
+    unsigned long long *pinned = nullptr;   // host-pinned readback words
     DBuf<uint64_t> unit_key;
     DBuf<int32_t> unit_entries;
     DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
@@ -132,6 +134,8 @@ struct skm_quant {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t chunk_ev[2] = {nullptr, nullptr};
+    unsigned long long *pinned = nullptr;     // host-pinned readback of the control block
     std::mutex mu;
     int64_t n_tx = 0, n_classes = 0, n_ids = 0, n_rows = 0;
     DBuf<int64_t> cls_offset, row_start, tx_row;
@@ -345,7 +349,7 @@ extern "C" int skm_index_info(const skm_index *ix, int64_t info[6])
 namespace {
 
 constexpr int CTR_ARENA = 0, CTR_CLASSES = 1, CTR_UNALIGNED = 2, CTR_UNITS = 3, CTR_LISTED = 4,
-              CTR_DEFERRED = 5, CTR_FLD = 8;
+              CTR_DEFERRED = 5, CTR_CREATED = 6, CTR_FLD = 8;
 constexpr int CTR_WORDS = 8 + MAX_FRAGMENT_LENGTH;
 constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2096;
 
@@ -518,8 +522,8 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         launch_map_units(ix->d, b, m->grid_blocks, m->want_stats, m->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(m->ev[2], m->stream));
-        unsigned long long cursor_and_flag[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(cursor_and_flag, b.ids_cursor, sizeof(cursor_and_flag), hipMemcpyDeviceToHost, m->stream));
+        unsigned long long *cursor_and_flag = m->pinned + 32;
+        HIP_TRY(hipMemcpyAsync(cursor_and_flag, b.ids_cursor, 16, hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
         ids = cursor_and_flag[0];
         if (cursor_and_flag[1]) return fail(SKM_ERR_STATE, "map kernel: the in-kernel scheduler stalled");
@@ -538,44 +542,38 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(table_reserve(m, n_units));
     SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)ids + 1024), true, m->stream));
     bind_table(m, m->t.slot_mask + 1);
+    const size_t scan_bytes = device_scan_u64_temp_bytes(n_units);
+    SKM_TRY(m->scan_temp.ensure(scan_bytes + 16));
     for (int pass = 0;; ++pass) {
+        // insert -> prefix sum over the creators -> commit -> totals -> verify: one pipeline,
+        // one synchronisation; the optimistic case needs a single pass
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
         launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, m->unit_claim.p, pass > 0, m->stream);
-        HIP_TRY(hipGetLastError());
-        // registry index and arena offset of every class created in this pass
-        unsigned long long created = 0;
-        if (device_exclusive_scan_u64(m->unit_claim.p, m->claim_scan.p, n_units, &created, m->stream))
+        if (device_exclusive_scan_u64(m->unit_claim.p, m->claim_scan.p, n_units, m->counters.p + CTR_CREATED,
+                                      m->scan_temp.p, scan_bytes, m->stream))
             return fail(SKM_ERR_HIP, "prefix sum over the new classes failed: %s", hipGetErrorString(hipGetLastError()));
-        const int64_t new_classes = (int64_t)(created >> 40);
-        const int64_t new_ids = (int64_t)(created & ((1ULL << 40) - 1));
-        launch_class_commit(m->t, b, m->unit_slot.p, m->unit_claim.p, m->claim_scan.p, m->host_classes,
-                            m->host_arena_used, m->stream);
+        launch_class_commit(m->t, b, m->unit_slot.p, m->unit_claim.p, m->claim_scan.p,
+                            m->counters.p + CTR_CREATED, pass == 0, m->stream);
+        launch_class_verify(m->t, b, m->unit_slot.p, m->stream);
         HIP_TRY(hipGetLastError());
-        m->host_classes += new_classes;
-        m->host_arena_used += new_ids;
-        unsigned long long totals[2] = {(unsigned long long)m->host_arena_used, (unsigned long long)m->host_classes};
-        HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_ARENA, &totals[0], 8, hipMemcpyHostToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_CLASSES, &totals[1], 8, hipMemcpyHostToDevice, m->stream));
-        HIP_TRY(hipMemcpyAsync(m->counters.p + CTR_LISTED, &totals[1], 8, hipMemcpyHostToDevice, m->stream));
-        unsigned long long deferred = 0;
-        HIP_TRY(hipMemcpyAsync(&deferred, m->counters.p + CTR_DEFERRED, 8, hipMemcpyDeviceToHost, m->stream));
+        if (pass == 0) HIP_TRY(hipEventRecord(m->ev[3], m->stream));
+        HIP_TRY(hipMemcpyAsync(m->pinned, m->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->pinned + 16, m->error.p, sizeof(int), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
-        if (deferred == 0) break;
+        const int err = *reinterpret_cast<int *>(m->pinned + 16);
+        if (err == SKM_ERR_COLLISION)
+            return fail(SKM_ERR_COLLISION, "two different class tuples share a 64-bit key");
+        if (err) return fail(err, "class table kernel reported error %d", err);
+        m->host_arena_used = (int64_t)m->pinned[CTR_ARENA];
+        m->host_classes = (int64_t)m->pinned[CTR_CLASSES];
+        if (m->pinned[CTR_LISTED] != m->pinned[CTR_CLASSES])
+            return fail(SKM_ERR_STATE, "class registry out of step (%llu listed, %llu classes)",
+                        m->pinned[CTR_LISTED], m->pinned[CTR_CLASSES]);
+        if (m->pinned[CTR_DEFERRED] == 0) break;
         if (pass > 40) return fail(SKM_ERR_STATE, "class table cannot absorb the batch");
         // too full for bounded probing: grow 4x (its classes move along), retry the deferred units
         SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 4, n_units));
     }
-    launch_class_verify(m->t, b, m->unit_slot.p, m->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(m->ev[3], m->stream));
-    unsigned long long ctr[8];
-    HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
-    SKM_TRY(read_error(m));
-    m->host_arena_used = (int64_t)ctr[CTR_ARENA];
-    m->host_classes = (int64_t)ctr[CTR_CLASSES];
-    if (ctr[CTR_LISTED] != ctr[CTR_CLASSES])
-        return fail(SKM_ERR_STATE, "class registry out of step (%llu listed, %llu classes)",
-                    ctr[CTR_LISTED], ctr[CTR_CLASSES]);
     // keep the load below 0.5 for the next batch
     if ((uint64_t)m->host_classes * 2 > m->t.slot_mask + 1)
         SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 2, 0));
@@ -598,6 +596,7 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     m->ix = ix;
     HIP_TRY(pool_stream_acquire(&m->stream));
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipHostMalloc((void **)&m->pinned, 64 * sizeof(unsigned long long)));
     m->want_stats = getenv("SKM_MAP_STATS") != nullptr;
     if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "start,lookup,merge,left,right,emit"
         sscanf(v, "%d,%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4],
@@ -619,8 +618,10 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->error.release(); m->bases.release(); m->offsets.release(); m->records.release();
     m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();
     m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
-    m->unit_slot.release(); m->unit_claim.release(); m->claim_scan.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
+    m->unit_slot.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
+    if (m->pinned) (void)hipHostFree(m->pinned);
+    m->unit_claim.release(); m->claim_scan.release(); m->scan_temp.release();
     pool_stream_release(m->stream);
     delete m;
     return SKM_OK;
@@ -908,6 +909,8 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     q->n_ids = n_ids;
     HIP_TRY(pool_stream_acquire(&q->stream));
     for (auto &e : q->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : q->chunk_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **)&q->pinned, 64 * sizeof(unsigned long long)));
     const size_t C = (size_t)std::max<int64_t>(n_classes, 1), M = (size_t)std::max<int64_t>(n_ids, 1);
     const size_t T = (size_t)std::max<int64_t>(n_tx, 1);
     const size_t R = (size_t)quant_rows_upper_bound(n_tx, n_ids);
@@ -948,13 +951,11 @@ QuantBuild quant_build_view(skm_quant *q)
     return b;
 }
 
-int quant_transpose(skm_quant *q)
+int quant_finish_setup(skm_quant *q, const ClassTable *table)
 {
     QuantBuild b = quant_build_view(q);
-    if (quant_localize(b, q->perm.p, q->stream) != 0)
-        return fail(SKM_ERR_HIP, "ordering the classes for locality failed: %s", hipGetErrorString(hipGetLastError()));
-    const int64_t rows = quant_build_transpose(b, q->stream);
-    if (rows < 0) return fail(SKM_ERR_HIP, "building the transcript-major class view failed (%lld): %s",
+    const int64_t rows = quant_setup(table, b, q->perm.p, q->stream);
+    if (rows < 0) return fail(SKM_ERR_HIP, "building the class views failed (%lld): %s",
                               (long long)rows, hipGetErrorString(hipGetLastError()));
     q->n_rows = rows;
     return SKM_OK;
@@ -1047,11 +1048,14 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     EmProblem p = em_problem(q, rel_tol, x_floor, max_iters, fixed_iters);
     p.n_total = n_total;
     HIP_TRY(hipMemsetAsync(q->ctl.p, 0, 16 * 8, q->stream));
-    unsigned long long ctl[8] = {0};
     int64_t k = 0;
-    const int64_t chunk = fixed_iters > 0 ? std::min<int64_t>(fixed_iters, 16) : 8;
+    const int64_t chunk = fixed_iters > 0 ? std::min<int64_t>(fixed_iters, 16) : 16;
     HIP_TRY(hipEventRecord(q->ev[0], q->stream));
-    for (;;) {
+    // Steps are enqueued in chunks; after each chunk the control block is copied to pinned
+    // memory and an event recorded.  The host stays one chunk ahead: chunk i+1 is already
+    // queued when it waits for chunk i's verdict, so the GPU never idles at a check-point
+    // (a converged EM turns at most one chunk of launches into no-ops).
+    auto enqueue_chunk = [&](int slot) -> int {
         for (int64_t i = 0; i < chunk; ++i, ++k) {
             launch_em_inner(p, (int)(k & 1), q->stream);
             launch_em_rows(p, (int)(k & 1), q->stream);
@@ -1061,13 +1065,23 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
                                           q->comm, q->stream));
             }
             launch_em_finalize(p, (int)(k & 1), q->comm != nullptr, q->stream);
-            q->launches += q->comm ? 4 : 3;
+            q->launches += q->comm ? 5 : 4;
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(ctl, q->ctl.p, sizeof(ctl), hipMemcpyDeviceToHost, q->stream));
-        HIP_TRY(hipStreamSynchronize(q->stream));
+        HIP_TRY(hipMemcpyAsync(q->pinned + 8 * slot, q->ctl.p, 8 * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipEventRecord(q->chunk_ev[slot], q->stream));
+        return SKM_OK;
+    };
+    unsigned long long ctl[8] = {0};
+    SKM_TRY(enqueue_chunk(0));
+    for (int slot = 0;; slot ^= 1) {
+        SKM_TRY(enqueue_chunk(slot ^ 1));                 // stay one chunk ahead
+        HIP_TRY(hipEventSynchronize(q->chunk_ev[slot]));
+        memcpy(ctl, q->pinned + 8 * slot, sizeof(ctl));
         if (ctl[0]) break;
     }
+    HIP_TRY(hipStreamSynchronize(q->stream));             // drain the look-ahead chunk (no-ops)
     HIP_TRY(hipEventRecord(q->ev[1], q->stream));
     HIP_TRY(hipEventSynchronize(q->ev[1]));
     float ms = 0;
@@ -1113,7 +1127,7 @@ extern "C" int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
         if (M) HIP_TRY(hipMemcpy(q->ids.p, class_targets + class_offsets[0], M * 4, hipMemcpyHostToDevice));
     }
     q->n_total = total;
-    rc = quant_transpose(q);
+    rc = quant_finish_setup(q, nullptr);
     if (rc != SKM_OK) { skm_quant_destroy(q); return rc; }
     *out = q;
     return SKM_OK;
@@ -1131,13 +1145,7 @@ extern "C" int skm_quant_create_from_mapper(skm_mapper *m, int64_t n_tx, skm_qua
     unsigned long long ctr[4];
     HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));
     q->n_total = (double)(ctr[CTR_UNITS] - ctr[CTR_UNALIGNED]);
-    QuantBuild b = quant_build_view(q);
-    rc = quant_build_from_table(m->t, C, M, b, q->stream);
-    if (rc != 0) {
-        skm_quant_destroy(q);
-        return fail(SKM_ERR_HIP, "ordering the class table failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
-    }
-    rc = quant_transpose(q);
+    rc = quant_finish_setup(q, &m->t);
     if (rc != SKM_OK) { skm_quant_destroy(q); return rc; }
     *out = q;
     return SKM_OK;
@@ -1154,6 +1162,8 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
     q->cum.release(); q->draw.release();
     for (auto &e : q->ev) (void)hipEventDestroy(e);
+    for (auto &e : q->chunk_ev) (void)hipEventDestroy(e);
+    if (q->pinned) (void)hipHostFree(q->pinned);
     pool_stream_release(q->stream);
     delete q;
     return SKM_OK;

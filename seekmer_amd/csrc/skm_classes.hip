@@ -92,12 +92,14 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
         atomicAdd(t.n_units, (unsigned long long)b.n_units);
 }
 
-// creators copy their tuple to the arena position the prefix sum assigned
+// creators copy their tuple to the arena position the prefix sum assigned,
+// counted from the table's current totals (device counters; stable during this launch)
 __global__ void __launch_bounds__(256)
 class_commit_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot,
-                    const unsigned long long *unit_claim, const unsigned long long *claim_scan,
-                    int64_t class_base, int64_t arena_base)
+                    const unsigned long long *unit_claim, const unsigned long long *claim_scan)
 {
+    const long long class_base = (long long)*t.n_listed;
+    const long long arena_base = (long long)*t.arena_cursor;
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
         if (unit_claim[u] == 0) continue;
@@ -117,6 +119,23 @@ class_commit_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot,
     }
 }
 
+// after the commit: the table's totals move on by what was created (and, once per
+// batch, the batch histogram is merged: merge_fragment_lengths, mapper.py:106-115)
+__global__ void __launch_bounds__(256)
+class_totals_kernel(ClassTable t, MapBatch b, const unsigned long long *created, bool merge_fld)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long c = *created;
+        *t.arena_cursor += c & ((1ULL << 40) - 1);
+        *t.n_listed += c >> 40;
+        *t.n_classes += c >> 40;
+    }
+    if (merge_fld)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_FRAGMENT_LENGTH;
+             i += gridDim.x * blockDim.x)
+            t.global_fld[i] += b.fld[i];
+}
+
 __global__ void __launch_bounds__(256)
 class_verify_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot)
 {
@@ -133,10 +152,6 @@ class_verify_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot)
             for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
         }
         if (!same) atomicExch(t.error, SKM_ERR_COLLISION);
-    }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_FRAGMENT_LENGTH;
-         i += gridDim.x * blockDim.x) {
-        t.global_fld[i] += b.fld[i];     // merge_fragment_lengths, mapper.py:106-115
     }
 }
 
@@ -255,11 +270,12 @@ void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_ba
 
 void launch_class_commit(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
                          const unsigned long long *unit_claim, const unsigned long long *claim_scan,
-                         int64_t class_base, int64_t arena_base, hipStream_t stream)
+                         const unsigned long long *created, bool merge_fld, hipStream_t stream)
 {
     if (b.n_units == 0) return;
     hipLaunchKernelGGL(class_commit_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
-                       unit_slot, unit_claim, claim_scan, class_base, arena_base);
+                       unit_slot, unit_claim, claim_scan);
+    hipLaunchKernelGGL(class_totals_kernel, dim3(8), dim3(256), 0, stream, t, b, created, merge_fld);
 }
 
 void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,

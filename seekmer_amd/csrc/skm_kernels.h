@@ -69,10 +69,12 @@ void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_ba
                          hipStream_t stream);
 void launch_class_commit(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
                          const unsigned long long *unit_claim, const unsigned long long *claim_scan,
-                         int64_t class_base, int64_t arena_base, hipStream_t stream);
-// exclusive prefix sum of n u64 values (hipCUB); *total = sum of all
+                         const unsigned long long *created, bool merge_fld, hipStream_t stream);
+// exclusive prefix sum of n u64 values (hipCUB), asynchronous; *total_device (HBM) = sum of all
+size_t device_scan_u64_temp_bytes(int64_t n);
 int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
-                              unsigned long long *total, hipStream_t stream);
+                              unsigned long long *total_device, void *temp, size_t temp_bytes,
+                              hipStream_t stream);
 void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
                          hipStream_t stream);
 void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,
@@ -131,16 +133,13 @@ struct QuantBuild {
     int32_t *row_tx;              // [R]   out
     int64_t n_rows_cap;
 };
-// classes taken from a mapper's table, ordered by first-seen unit (the reference's class order)
-int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids, QuantBuild &q,
-                           hipStream_t stream);
-// stable reorder of the classes by smallest transcript id (gather locality); perm[k] = caller index
-int quant_localize(QuantBuild &q, int32_t *perm, hipStream_t stream);
-// y[k] = x[perm[k]] (gather) or y[perm[k]] = x[k] (scatter), n doubles / u64
+// One asynchronous pipeline: (classes from a mapper's table in first-seen order when `table` is
+// given) -> stable reorder by smallest transcript id (gather locality; perm[k] = caller's index of
+// internal class k) -> transcript-major rows.  Returns the number of rows, or < 0.
+int64_t quant_setup(const ClassTable *table, QuantBuild &q, int32_t *perm, hipStream_t stream);
+// y[k] = x[perm[k]] (gather) or y[perm[k]] = x[k] (scatter), n doubles
 void launch_permute_f64(const double *x, const int32_t *perm, int64_t n, double *y, bool scatter,
                         hipStream_t stream);
-// builds tx_cls / tx_row / row_* from cls_offset + ids; returns the number of rows (or < 0)
-int64_t quant_build_transpose(QuantBuild &q, hipStream_t stream);
 int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids);
 
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,

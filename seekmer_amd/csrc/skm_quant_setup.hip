@@ -8,17 +8,34 @@
 #include "skm_pool.h"
 
 #include <hipcub/hipcub.hpp>
+#include <vector>
 
 namespace skm {
 
 namespace {
 
-template <class T>
-struct Tmp {
-    T *p = nullptr;
-    hipError_t alloc(size_t n) { return pool_alloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)); }
-    ~Tmp() { pool_free(p); }
+// Temporaries of one setup call: handed out from the caching pool, given back
+// together after ONE stream synchronisation at the end (the setup is a single
+// asynchronous pipeline; nothing in between needs the host).
+struct Scratch {
+    hipStream_t stream;
+    std::vector<void *> held;
+    explicit Scratch(hipStream_t s) : stream(s) {}
+    template <class T>
+    T *alloc(size_t n)
+    {
+        void *p = nullptr;
+        if (pool_alloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        held.push_back(p);
+        return static_cast<T *>(p);
+    }
+    ~Scratch()
+    {
+        (void)hipStreamSynchronize(stream);
+        for (void *p : held) pool_free(p);
+    }
 };
+#define QB_ALLOC(var, type, n) type *var = scratch.alloc<type>(n); if (!var) return -1
 
 #define QB_TRY(call) do { if ((call) != hipSuccess) return -1; } while (0)
 
@@ -69,6 +86,13 @@ copy_tuples_kernel(const int32_t *perm, int64_t n, const int64_t *arena_off, con
         const int64_t len = cls_offset[k + 1] - dst;
         for (int64_t j = 0; j < len; ++j) ids[dst + j] = arena[src + j];
     }
+}
+
+__global__ void __launch_bounds__(64)
+sum_last_kernel(const unsigned long long *in, const unsigned long long *scan, int64_t n,
+                unsigned long long *total)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = in[n - 1] + scan[n - 1];
 }
 
 __global__ void __launch_bounds__(256)
@@ -159,41 +183,55 @@ inline unsigned blocks_for(int64_t n)
     return (unsigned)b;
 }
 
-// exclusive scan of n int64 values into out[0..n) and the total into out[n]
-int exclusive_scan_with_total(const int64_t *in, int64_t *out, int64_t n, hipStream_t stream)
+// exclusive scan of n int64 values into out[0..n) and the total into out[n] (all on the stream)
+int exclusive_scan_with_total(Scratch &scratch, const int64_t *in, int64_t *out, int64_t n)
 {
+    hipStream_t stream = scratch.stream;
     if (n == 0) {
         QB_TRY(hipMemsetAsync(out, 0, sizeof(int64_t), stream));
         return 0;
     }
     size_t bytes = 0;
     QB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, stream));
-    Tmp<char> tmp;
-    QB_TRY(tmp.alloc(bytes));
-    QB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, stream));
+    QB_ALLOC(tmp, char, bytes);
+    QB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, stream));
     hipLaunchKernelGGL(set_last_offset_kernel, dim3(1), dim3(64), 0, stream, out, in, n);
-    QB_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+template <class K>
+int sort_pairs(Scratch &scratch, const K *keys_in, K *keys_out, const int32_t *vals_in, int32_t *vals_out,
+               int64_t n, int end_bit)
+{
+    size_t bytes = 0;
+    QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0,
+                                             end_bit, scratch.stream));
+    QB_ALLOC(tmp, char, bytes);
+    QB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0,
+                                             end_bit, scratch.stream));
     return 0;
 }
 
 }  // namespace
 
-int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
-                              unsigned long long *total, hipStream_t stream)
+size_t device_scan_u64_temp_bytes(int64_t n)
 {
-    *total = 0;
-    if (n == 0) return 0;
-    if (n >= (1LL << 31)) return -2;
     size_t bytes = 0;
-    QB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, stream));
-    Tmp<char> tmp;
-    QB_TRY(tmp.alloc(bytes));
-    QB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, stream));
-    unsigned long long last_in = 0, last_out = 0;
-    QB_TRY(hipMemcpyAsync(&last_in, in + n - 1, 8, hipMemcpyDeviceToHost, stream));
-    QB_TRY(hipMemcpyAsync(&last_out, out + n - 1, 8, hipMemcpyDeviceToHost, stream));
-    QB_TRY(hipStreamSynchronize(stream));
-    *total = last_in + last_out;
+    unsigned long long *p = nullptr;
+    if (n <= 0 || n >= (1LL << 31)) return 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, p, p, (int)n, nullptr) != hipSuccess) return 0;
+    return bytes;
+}
+
+// out = exclusive prefix sum of in[0..n); *total_device (HBM) = sum of all; asynchronous
+int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
+                              unsigned long long *total_device, void *temp, size_t temp_bytes,
+                              hipStream_t stream)
+{
+    if (n == 0) { QB_TRY(hipMemsetAsync(total_device, 0, 8, stream)); return 0; }
+    if (n >= (1LL << 31)) return -2;
+    QB_TRY(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, stream));
+    hipLaunchKernelGGL(sum_last_kernel, dim3(1), dim3(64), 0, stream, in, out, n, total_device);
     return 0;
 }
 
@@ -202,39 +240,30 @@ int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids)
     return n_tx + n_ids / EM_ROW_CAP + 1;
 }
 
-int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids, QuantBuild &q,
-                           hipStream_t stream)
+namespace {
+
+int build_from_table(Scratch &scratch, const ClassTable &t, QuantBuild &q)
 {
+    hipStream_t stream = scratch.stream;
+    const int64_t n_classes = q.n_classes;
     if (n_classes == 0) {
         QB_TRY(hipMemsetAsync(q.cls_offset, 0, sizeof(int64_t), stream));
         return 0;
     }
-    if (n_classes >= (1LL << 31) || n_ids >= (1LL << 31)) return -2;
-    Tmp<int64_t> arena_off, len, len_sorted;
-    Tmp<double> count;
-    Tmp<unsigned long long> first, first_sorted;
-    Tmp<int32_t> iota, perm;
-    QB_TRY(arena_off.alloc(n_classes)); QB_TRY(len.alloc(n_classes)); QB_TRY(len_sorted.alloc(n_classes));
-    QB_TRY(count.alloc(n_classes)); QB_TRY(first.alloc(n_classes)); QB_TRY(first_sorted.alloc(n_classes));
-    QB_TRY(iota.alloc(n_classes)); QB_TRY(perm.alloc(n_classes));
+    if (n_classes >= (1LL << 31) || q.n_ids >= (1LL << 31)) return -2;
+    QB_ALLOC(arena_off, int64_t, n_classes); QB_ALLOC(len, int64_t, n_classes);
+    QB_ALLOC(len_sorted, int64_t, n_classes); QB_ALLOC(count, double, n_classes);
+    QB_ALLOC(first, unsigned long long, n_classes); QB_ALLOC(first_sorted, unsigned long long, n_classes);
+    QB_ALLOC(iota, int32_t, n_classes); QB_ALLOC(perm, int32_t, n_classes);
     hipLaunchKernelGGL(table_dump_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream,
-                       t, n_classes, arena_off.p, len.p, count.p, first.p);
-    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, iota.p, n_classes);
-    size_t bytes = 0;
-    QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, first.p, first_sorted.p, iota.p, perm.p,
-                                             (int)n_classes, 0, 64, stream));
-    Tmp<char> tmp;
-    QB_TRY(tmp.alloc(bytes));
-    QB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, first.p, first_sorted.p, iota.p, perm.p,
-                                             (int)n_classes, 0, 64, stream));
-    hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm.p,
-                       n_classes, len.p, count.p, len_sorted.p, q.cls_count);
-    if (exclusive_scan_with_total(len_sorted.p, q.cls_offset, n_classes, stream)) return -1;
-    hipLaunchKernelGGL(copy_tuples_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm.p,
-                       n_classes, arena_off.p, t.arena, q.cls_offset, q.ids);
-    QB_TRY(hipGetLastError());
-    QB_TRY(hipStreamSynchronize(stream));
-    (void)n_ids;
+                       t, n_classes, arena_off, len, count, first);
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, iota, n_classes);
+    if (sort_pairs(scratch, first, first_sorted, iota, perm, n_classes, 64)) return -1;
+    hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm,
+                       n_classes, len, count, len_sorted, q.cls_count);
+    if (exclusive_scan_with_total(scratch, len_sorted, q.cls_offset, n_classes)) return -1;
+    hipLaunchKernelGGL(copy_tuples_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm,
+                       n_classes, arena_off, t.arena, q.cls_offset, q.ids);
     return 0;
 }
 
@@ -244,76 +273,74 @@ int quant_build_from_table(const ClassTable &t, int64_t n_classes, int64_t n_ids
 // classes that share transcripts then sit in neighbouring cache sectors
 // instead of being spread over the whole first-seen order.  perm[k] = index of
 // internal class k in the caller's order.
-int quant_localize(QuantBuild &q, int32_t *perm, hipStream_t stream)
+int localize(Scratch &scratch, QuantBuild &q, int32_t *perm)
 {
+    hipStream_t stream = scratch.stream;
     const int64_t C = q.n_classes, M = q.n_ids;
     if (C == 0) return 0;
     if (C >= (1LL << 31) || M >= (1LL << 31)) return -2;
-    Tmp<uint32_t> key, key_sorted;
-    Tmp<int32_t> iota, ids_copy;
-    Tmp<int64_t> len, len_sorted, old_offset;
-    Tmp<double> count_copy;
-    QB_TRY(key.alloc(C)); QB_TRY(key_sorted.alloc(C)); QB_TRY(iota.alloc(C)); QB_TRY(ids_copy.alloc(M));
-    QB_TRY(len.alloc(C)); QB_TRY(len_sorted.alloc(C)); QB_TRY(old_offset.alloc(C + 1)); QB_TRY(count_copy.alloc(C));
+    QB_ALLOC(key, uint32_t, C); QB_ALLOC(key_sorted, uint32_t, C); QB_ALLOC(iota, int32_t, C);
+    QB_ALLOC(ids_copy, int32_t, M); QB_ALLOC(len, int64_t, C); QB_ALLOC(len_sorted, int64_t, C);
+    QB_ALLOC(old_offset, int64_t, C + 1); QB_ALLOC(count_copy, double, C);
     hipLaunchKernelGGL(class_min_id_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, q.cls_offset, q.ids, C,
-                       key.p, len.p);
-    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, iota.p, C);
+                       key, len);
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, iota, C);
     int end_bit = 1;
     while ((1LL << end_bit) < q.n_tx && end_bit < 32) ++end_bit;
-    size_t bytes = 0;
-    QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key.p, key_sorted.p, iota.p, perm, (int)C, 0,
-                                             end_bit, stream));
-    Tmp<char> tmp;
-    QB_TRY(tmp.alloc(bytes));
-    QB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, key.p, key_sorted.p, iota.p, perm, (int)C, 0,
-                                             end_bit, stream));
-    QB_TRY(hipMemcpyAsync(old_offset.p, q.cls_offset, (C + 1) * 8, hipMemcpyDeviceToDevice, stream));
-    QB_TRY(hipMemcpyAsync(ids_copy.p, q.ids, M * 4, hipMemcpyDeviceToDevice, stream));
-    QB_TRY(hipMemcpyAsync(count_copy.p, q.cls_count, C * 8, hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, perm, C, len.p,
-                       count_copy.p, len_sorted.p, q.cls_count);
-    if (exclusive_scan_with_total(len_sorted.p, q.cls_offset, C, stream)) return -1;
+    if (sort_pairs(scratch, key, key_sorted, iota, perm, C, end_bit)) return -1;
+    QB_TRY(hipMemcpyAsync(old_offset, q.cls_offset, (C + 1) * 8, hipMemcpyDeviceToDevice, stream));
+    QB_TRY(hipMemcpyAsync(ids_copy, q.ids, M * 4, hipMemcpyDeviceToDevice, stream));
+    QB_TRY(hipMemcpyAsync(count_copy, q.cls_count, C * 8, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, perm, C, len,
+                       count_copy, len_sorted, q.cls_count);
+    if (exclusive_scan_with_total(scratch, len_sorted, q.cls_offset, C)) return -1;
     hipLaunchKernelGGL(copy_tuples_by_offset_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, perm, C,
-                       old_offset.p, ids_copy.p, q.cls_offset, q.ids);
-    QB_TRY(hipGetLastError());
-    QB_TRY(hipStreamSynchronize(stream));
+                       old_offset, ids_copy, q.cls_offset, q.ids);
     return 0;
 }
 
-int64_t quant_build_transpose(QuantBuild &q, hipStream_t stream)
+int transpose(Scratch &scratch, QuantBuild &q)
 {
+    hipStream_t stream = scratch.stream;
     const int64_t C = q.n_classes, M = q.n_ids, T = q.n_tx;
     if (M >= (1LL << 31) || C >= (1LL << 31)) return -2;
-    Tmp<int32_t> pair_cls, sorted_tx;
-    Tmp<int64_t> tx_offset, rows;
-    QB_TRY(pair_cls.alloc(M)); QB_TRY(sorted_tx.alloc(M));
-    QB_TRY(tx_offset.alloc(T + 1)); QB_TRY(rows.alloc(T));
+    QB_ALLOC(pair_cls, int32_t, M); QB_ALLOC(sorted_tx, int32_t, M);
+    QB_ALLOC(tx_offset, int64_t, T + 1); QB_ALLOC(rows, int64_t, T);
     if (M > 0) {
         hipLaunchKernelGGL(pair_class_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, q.cls_offset, C,
-                           pair_cls.p);
+                           pair_cls);
         int end_bit = 1;
         while ((1LL << end_bit) < T && end_bit < 31) ++end_bit;
-        size_t bytes = 0;
-        QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, q.ids, sorted_tx.p, pair_cls.p, q.tx_cls,
-                                                 (int)M, 0, end_bit, stream));
-        Tmp<char> tmp;
-        QB_TRY(tmp.alloc(bytes));
-        QB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, q.ids, sorted_tx.p, pair_cls.p, q.tx_cls,
-                                                 (int)M, 0, end_bit, stream));
-        QB_TRY(hipStreamSynchronize(stream));
+        if (sort_pairs(scratch, q.ids, sorted_tx, pair_cls, q.tx_cls, M, end_bit)) return -1;
     }
-    hipLaunchKernelGGL(segment_starts_kernel, dim3(blocks_for(M + 1)), dim3(256), 0, stream, sorted_tx.p, M,
-                       T, tx_offset.p);
-    hipLaunchKernelGGL(row_count_kernel, dim3(blocks_for(T)), dim3(256), 0, stream, tx_offset.p, T, rows.p);
-    if (exclusive_scan_with_total(rows.p, q.tx_row, T, stream)) return -1;
-    int64_t n_rows = 0;
-    QB_TRY(hipMemcpyAsync(&n_rows, q.tx_row + T, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    QB_TRY(hipStreamSynchronize(stream));
-    if (n_rows > q.n_rows_cap) return -3;
-    hipLaunchKernelGGL(row_fill_kernel, dim3(blocks_for(T)), dim3(256), 0, stream, tx_offset.p, q.tx_row, T,
+    hipLaunchKernelGGL(segment_starts_kernel, dim3(blocks_for(M + 1)), dim3(256), 0, stream, sorted_tx, M,
+                       T, tx_offset);
+    hipLaunchKernelGGL(row_count_kernel, dim3(blocks_for(T)), dim3(256), 0, stream, tx_offset, T, rows);
+    if (exclusive_scan_with_total(scratch, rows, q.tx_row, T)) return -1;
+    // rows <= T + M / EM_ROW_CAP, which is what row_start / row_tx were sized for
+    hipLaunchKernelGGL(row_fill_kernel, dim3(blocks_for(T)), dim3(256), 0, stream, tx_offset, q.tx_row, T,
                        M, q.row_start, q.row_tx);
-    QB_TRY(hipGetLastError());
-    QB_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+}  // namespace
+
+// The whole setup as one asynchronous pipeline on `stream`: (classes from the
+// mapper's table in first-seen order, when `table` is given) -> locality order
+// -> transcript-major rows.  One synchronisation at the end; returns the number
+// of rows or a negative code.
+int64_t quant_setup(const ClassTable *table, QuantBuild &q, int32_t *perm, hipStream_t stream)
+{
+    int64_t n_rows = -1;
+    {
+        Scratch scratch(stream);
+        if (table && build_from_table(scratch, *table, q)) return -1;
+        if (localize(scratch, q, perm)) return -1;
+        if (transpose(scratch, q)) return -1;
+        QB_TRY(hipGetLastError());
+        QB_TRY(hipMemcpyAsync(&n_rows, q.tx_row + q.n_tx, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    }                                  // ~Scratch: the single synchronisation
+    if (n_rows > q.n_rows_cap) return -3;
     return n_rows;
 }
 
