@@ -73,8 +73,10 @@ int skm_index_create(const void *kmers, int64_t n_slots,
                      int device, skm_index **out);
 int skm_index_destroy(skm_index *index);
 /* info[0]=n_slots [1]=n_contigs [2]=n_bases [3]=n_targets [4]=max target_count
- * [5]=device bytes held */
-int skm_index_info(const skm_index *index, int64_t info[6]);
+ * [5]=device bytes held [6]=1 when every contig's first_kmer/last_kmer spell
+ * its first/last k pooled bases (the mapper then takes 8-base windows at contig
+ * ends from the contig row instead of the pool) [7]=reserved */
+int skm_index_info(const skm_index *index, int64_t info[8]);
 
 /* ------------------------------------------------------------------ mapper
  * One handle = ReadMapper + the MapResult it feeds
@@ -208,6 +210,13 @@ int skm_fastq_open(const char *const *paths, int n_paths, int paired,
 int skm_fastq_next(skm_fastq *reader, int64_t *n_units, const char **bases,
                    const int64_t **offsets, const char **names,
                    const int64_t **name_offsets);
+/* Keep the arrays of the last skm_fastq_next alive past the next call: the
+ * reader hands their storage over as *slab and fills another one from now on.
+ * skm_fastq_recycle gives it back for re-use (reader NULL: just frees it) --
+ * a large batch costs more in first-touch page faults than in parsing. */
+typedef struct skm_fastq_slab skm_fastq_slab;
+int skm_fastq_detach(skm_fastq *reader, skm_fastq_slab **slab);
+int skm_fastq_recycle(skm_fastq *reader, skm_fastq_slab *slab);
 int skm_fastq_close(skm_fastq *reader);
 
 /* Seeded synthetic data; integer arithmetic only. */

@@ -90,6 +90,8 @@ HOST_SYMBOLS = {
                                       c_i64, c_void_pp]),
     'skm_fastq_next': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_void_pp, c_void_pp, c_void_pp,
                                       c_void_pp]),
+    'skm_fastq_detach': (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
+    'skm_fastq_recycle': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_close': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_synth_transcriptome': (ctypes.c_int, [ctypes.c_uint64, c_i64, c_i64p, c_void_pp,
                                                c_void_pp]),

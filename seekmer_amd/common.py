@@ -71,6 +71,14 @@ class KMerIndex:
                 self._handles[device] = handle
             return handle
 
+    def device_info(self, device=0):
+        """skm_index_info of the device copy, as a dict."""
+        info = (ctypes.c_int64 * 8)()
+        _native.check(_native.hip().skm_index_info(self.device_handle(device), info))
+        names = ('n_slots', 'n_contigs', 'n_bases', 'n_targets', 'max_target_count', 'device_bytes',
+                 'edge_windows')
+        return dict(zip(names, info))
+
     def release(self):
         with self._lock:
             for handle in self._handles.values():
@@ -237,10 +245,57 @@ class ReadBatch:
         return batch
 
 
+class _FastqReader:
+    """Owns one skm_fastq handle; closed when the feeder loop and every batch
+    that borrowed a slab from it are gone."""
+
+    def __init__(self, names, paired, batch_units):
+        array = (ctypes.c_char_p * len(names))(*names)
+        self.handle = ctypes.c_void_p()
+        self.lock = threading.Lock()
+        _native.check_host(_native.host().skm_fastq_open(
+            array, len(names), int(paired), batch_units, ctypes.byref(self.handle)),
+            'skm_fastq_open')
+
+    def recycle(self, slab):
+        with self.lock:
+            _native.host().skm_fastq_recycle(self.handle, slab)
+
+    def close(self):
+        with self.lock:
+            if self.handle:
+                _native.host().skm_fastq_close(self.handle)
+                self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Slab:
+    """Storage of one batch, detached from the reader (skm_fastq_detach) and
+    given back for re-use when the batch is dropped."""
+
+    def __init__(self, reader, slab):
+        self.reader = reader
+        self.slab = slab
+
+    def __del__(self):
+        try:
+            self.reader.recycle(self.slab)
+        except Exception:
+            pass
+
+
 class NativeReadFeeder:
     """FASTQ batches from the native reader (skm_fastq_*): the same batching
-    rule as the feeders above, without per-read Python objects.  Compressed
-    inputs are piped through zcat/bzcat/xzcat as the reference does."""
+    rule as the feeders above, without per-read Python objects.  The arrays of
+    a batch are views of a slab owned by the reader; the slab goes back to the
+    reader when the batch is dropped, so large batches do not pay for fresh
+    pages again.  Compressed inputs are piped through zcat/bzcat/xzcat as the
+    reference does."""
 
     def __init__(self, paths, paired, batch_units=BUFFER_SIZE):
         paths = [pathlib.Path(p) for p in paths]
@@ -253,6 +308,7 @@ class NativeReadFeeder:
     def __iter__(self):
         tools = {'.gz': 'zcat', '.bz2': 'bzcat', '.xz': 'xzcat', '.lzma': 'xzcat'}
         processes, names = [], []
+        host = _native.host()
         try:
             for path in self.paths:
                 if path.suffix in tools:
@@ -262,35 +318,34 @@ class NativeReadFeeder:
                     names.append(('/dev/fd/%d' % process.stdout.fileno()).encode())
                 else:
                     names.append(str(path).encode())
-            array = (ctypes.c_char_p * len(names))(*names)
-            reader = ctypes.c_void_p()
-            _native.check_host(_native.host().skm_fastq_open(
-                array, len(names), int(self.paired), self.batch_units, ctypes.byref(reader)),
-                'skm_fastq_open')
-            try:
-                n = ctypes.c_int64()
-                p_bases, p_off = ctypes.c_void_p(), ctypes.c_void_p()
-                p_names, p_noff = ctypes.c_void_p(), ctypes.c_void_p()
-                while True:
-                    _native.check_host(_native.host().skm_fastq_next(
-                        reader, ctypes.byref(n), ctypes.byref(p_bases), ctypes.byref(p_off),
-                        ctypes.byref(p_names), ctypes.byref(p_noff)), 'skm_fastq_next')
-                    if n.value == 0:
-                        break
-                    n_reads = n.value * (2 if self.paired else 1)
-                    offsets = numpy.ctypeslib.as_array(
-                        ctypes.cast(p_off, _native.c_i64p), (n_reads + 1,)).copy()
-                    bases = numpy.ctypeslib.as_array(
-                        ctypes.cast(p_bases, ctypes.POINTER(ctypes.c_uint8)),
-                        (int(offsets[-1]) + 1,)).copy()
-                    name_offsets = numpy.ctypeslib.as_array(
-                        ctypes.cast(p_noff, _native.c_i64p), (n.value + 1,)).copy()
-                    name_bytes = numpy.ctypeslib.as_array(
-                        ctypes.cast(p_names, ctypes.POINTER(ctypes.c_uint8)),
-                        (max(int(name_offsets[-1]), 1),)).copy()
-                    yield ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets)
-            finally:
-                _native.host().skm_fastq_close(reader)
+            reader = _FastqReader(names, self.paired, self.batch_units)
+            n = ctypes.c_int64()
+            p_bases, p_off = ctypes.c_void_p(), ctypes.c_void_p()
+            p_names, p_noff = ctypes.c_void_p(), ctypes.c_void_p()
+            while True:
+                _native.check_host(host.skm_fastq_next(
+                    reader.handle, ctypes.byref(n), ctypes.byref(p_bases), ctypes.byref(p_off),
+                    ctypes.byref(p_names), ctypes.byref(p_noff)), 'skm_fastq_next')
+                if n.value == 0:
+                    break
+                slab = ctypes.c_void_p()
+                _native.check_host(host.skm_fastq_detach(reader.handle, ctypes.byref(slab)),
+                                   'skm_fastq_detach')
+                owner = _Slab(reader, slab)
+                def view(pointer, count, ctype, dtype):
+                    # the array keeps the ctypes block alive and the block the slab
+                    block = (ctype * count).from_address(pointer.value)
+                    block._slab = owner
+                    return numpy.frombuffer(block, dtype=dtype)
+
+                n_reads = n.value * (2 if self.paired else 1)
+                offsets = view(p_off, n_reads + 1, ctypes.c_int64, numpy.int64)
+                bases = view(p_bases, int(offsets[-1]) + 1, ctypes.c_uint8, numpy.uint8)
+                name_offsets = view(p_noff, n.value + 1, ctypes.c_int64, numpy.int64)
+                name_bytes = view(p_names, max(int(name_offsets[-1]), 1), ctypes.c_uint8, numpy.uint8)
+                batch = ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets)
+                yield batch
+                del batch, owner, bases, offsets, name_bytes, name_offsets, view
         finally:
             for process in processes:
                 process.stdout.close()

@@ -264,13 +264,27 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     // host-side validation: every shape the kernels index with must be in range
     const ContigEntry *hc = (const ContigEntry *)contigs;
     int64_t max_tc = 0;
+    bool edge_windows = true;       // first_kmer / last_kmer spell the contig's first / last k bases
+    auto encode = [&](int64_t at) {                      // _kmer.pxd:46-68 over the pooled bases
+        uint64_t k = 0;
+        for (int i = 0; i < K; ++i) {
+            const unsigned ch = (unsigned char)sequences[at + i] & 0xDFu;
+            k = (k << 2) | (ch == 'T' ? 3u : ch == 'G' ? 2u : ch == 'C' ? 1u : 0u);
+        }
+        return k;
+    };
     for (int64_t c = 0; c < n_contigs; ++c) {
         if (hc[c].offset < 0 || hc[c].length < 0 || hc[c].offset + hc[c].length > n_bases
                 || hc[c].target_offset < 0 || hc[c].target_length < 0
                 || hc[c].target_offset + hc[c].target_length > n_targets)
             return fail(SKM_ERR_ARG, "contig %lld points outside the pooled arrays", (long long)c);
         max_tc = std::max<int64_t>(max_tc, hc[c].target_length);
+        if (edge_windows && (hc[c].length < K || encode(hc[c].offset) != hc[c].first_kmer
+                             || encode(hc[c].offset + hc[c].length - K) != hc[c].last_kmer))
+            edge_windows = false;
     }
+    if (max_tc >= (1LL << 22))
+        return fail(SKM_ERR_ARG, "a contig lists %lld targets (limit 4194303)", (long long)max_tc);
     const IndexEntry *hk = (const IndexEntry *)kmers;
     int64_t empty = 0;
     for (int64_t i = 0; i < n_slots; ++i) {
@@ -292,7 +306,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     char *d_ascii = nullptr;
     HIP_TRY(hipMalloc(&ix->kmers, (size_t)n_slots * sizeof(IndexEntry)));
     HIP_TRY(hipMalloc(&ix->contigs, (size_t)n_contigs * sizeof(DevContig)));
-    HIP_TRY(hipMalloc(&ix->targets, (size_t)std::max<int64_t>(n_targets, 1) * sizeof(Coord)));
+    HIP_TRY(hipMalloc(&ix->targets, (size_t)std::max<int64_t>(n_targets, 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ix->seq2, (size_t)n_words * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&d_ascii, (size_t)n_bases));
     HIP_TRY(hipMemcpy(ix->kmers, kmers, (size_t)n_slots * sizeof(IndexEntry), hipMemcpyHostToDevice));
@@ -300,8 +314,12 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     HIP_TRY(hipMalloc(&d_contigs48, (size_t)n_contigs * sizeof(ContigEntry)));
     HIP_TRY(hipMemcpy(d_contigs48, contigs, (size_t)n_contigs * sizeof(ContigEntry), hipMemcpyHostToDevice));
     launch_pack_contigs(d_contigs48, n_contigs, ix->contigs, nullptr);
-    if (n_targets)
-        HIP_TRY(hipMemcpy(ix->targets, targets, (size_t)n_targets * sizeof(Coord), hipMemcpyHostToDevice));
+    if (n_targets) {                // keep the signed entries only (half the sectors per slice)
+        std::vector<int32_t> entries((size_t)n_targets);
+        const Coord *ht = (const Coord *)targets;
+        for (int64_t i = 0; i < n_targets; ++i) entries[(size_t)i] = ht[i].entry;
+        HIP_TRY(hipMemcpy(ix->targets, entries.data(), (size_t)n_targets * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(d_ascii, sequences, (size_t)n_bases, hipMemcpyHostToDevice));
     launch_pack_sequences(d_ascii, n_bases, (uint64_t *)ix->seq2, n_words, nullptr);
     HIP_TRY(hipGetLastError());
@@ -315,11 +333,12 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     ix->d.n_contigs = n_contigs;
     ix->d.seq2 = (const uint64_t *)ix->seq2;
     ix->d.n_bases = n_bases;
-    ix->d.targets = (const Coord *)ix->targets;
+    ix->d.targets = (const int32_t *)ix->targets;
     ix->d.n_targets = n_targets;
     ix->d.max_target_count = (int32_t)std::max<int64_t>(max_tc, 1);
+    ix->d.edge_windows = edge_windows ? 1 : 0;
     ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(DevContig)
-                + n_targets * (int64_t)sizeof(Coord) + n_words * 8;
+                + n_targets * (int64_t)sizeof(int32_t) + n_words * 8;
     *out = ix;
     return SKM_OK;
 }
@@ -333,7 +352,7 @@ extern "C" int skm_index_destroy(skm_index *ix)
     return SKM_OK;
 }
 
-extern "C" int skm_index_info(const skm_index *ix, int64_t info[6])
+extern "C" int skm_index_info(const skm_index *ix, int64_t info[8])
 {
     if (!ix || !info) return fail(SKM_ERR_ARG, "NULL argument");
     info[0] = ix->n_slots;
@@ -342,6 +361,8 @@ extern "C" int skm_index_info(const skm_index *ix, int64_t info[6])
     info[3] = ix->d.n_targets;
     info[4] = ix->d.max_target_count;
     info[5] = ix->bytes;
+    info[6] = ix->d.edge_windows;
+    info[7] = 0;
     return SKM_OK;
 }
 

@@ -36,10 +36,11 @@ struct alignas(32) DevContig {
     uint64_t first_kmer, last_kmer;
 };
 
-// Index as it lives in HBM.  kmers/targets keep the reference's array layout;
-// contigs are re-packed (above) and the pooled contig bases go to 2 bits (32
+// Index as it lives in HBM.  kmers keeps the reference's array layout;
+// contigs are re-packed (above), the pooled contig bases go to 2 bits (32
 // bases per u64, first base in the top bits) because the mapper only ever
-// needs 8-base windows of them.
+// needs 8-base windows of them, and of each target (entry, offset) only the
+// signed transcript entry is kept: nothing on this path reads the offset.
 struct DevIndex {
     const IndexEntry *kmers;
     uint32_t slot_mask;
@@ -47,9 +48,10 @@ struct DevIndex {
     int64_t n_contigs;
     const uint64_t *seq2;      // 2-bit packed pooled bases, one zero pad word
     int64_t n_bases;
-    const Coord *targets;
+    const int32_t *targets;    // signed transcript entries (Coord.entry of the reference rows)
     int64_t n_targets;
     int32_t max_target_count;
+    int32_t edge_windows;      // first_kmer/last_kmer agree with the pooled bases on every contig
 };
 
 __device__ __forceinline__ Coord invalid_coord() { return Coord{0, -1}; }  // _coordinate.pxd:13-24
@@ -110,32 +112,39 @@ struct LaneStats {
 };
 
 // KMerIndex.map_kmer, _common.pyx:54-97.  Home slot = hash(min(kmer, rc)) &
-// (size-1); linear probe with wrap-around; empty slot ends the probe.  PROBE
-// consecutive slots are fetched per round trip (independent 16-byte loads) and
-// then examined in probe order: a chunk of 64 lookups waits for its slowest
-// lane, whose chain costs ceil(P/PROBE) memory latencies instead of P.  The
-// slots examined -- and the result -- are the reference's.
+// (size-1); linear probe with wrap-around; empty slot ends the probe.  The
+// table is read one aligned 64-byte sector (four slots) per round trip and the
+// slots are examined in probe order from the home slot on: the slots examined
+// -- and the result -- are the reference's, a chain that stays inside its
+// sector costs one sector visit, and a longer one costs ceil() memory
+// latencies instead of one per slot.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PROBE = 4;
 template <bool STATS>
 __device__ __forceinline__ Coord map_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
 {
     const uint64_t rc = kmer_revcomp(kmer);
-    uint32_t slot = kmer_hash(kmer < rc ? kmer : rc) & ix.slot_mask;
+    const uint32_t home = kmer_hash(kmer < rc ? kmer : rc) & ix.slot_mask;
     if (STATS) st->lookups++;
-    for (uint64_t n = 0; n <= ix.slot_mask; n += PROBE) {
-        uint4 raw[PROBE];
+    uint32_t base = home & ~(uint32_t)(PROBE - 1);
+    int skip = (int)(home & (PROBE - 1));
+    for (uint64_t n = 0; n <= ix.slot_mask;) {
+        u32x4 raw[PROBE];
 #pragma unroll
         for (int j = 0; j < PROBE; ++j)
-            raw[j] = *reinterpret_cast<const uint4 *>(&ix.kmers[(slot + j) & ix.slot_mask]);
+            raw[j] = *reinterpret_cast<const u32x4 *>(&ix.kmers[(base + j) & ix.slot_mask]);
 #pragma unroll
         for (int j = 0; j < PROBE; ++j) {
+            if (j < skip) continue;
             const uint64_t stored = ((uint64_t)raw[j].y << 32) | raw[j].x;
             if (STATS) st->slots++;
             if (stored == KMER_INVALID) return invalid_coord();
             if (stored == kmer) return Coord{(int32_t)raw[j].z, (int32_t)raw[j].w};
             if (stored == rc) return Coord{~(int32_t)raw[j].z, (int32_t)raw[j].w};
+            ++n;
         }
-        slot = (slot + PROBE) & ix.slot_mask;
+        skip = 0;
+        base = (base + PROBE) & ix.slot_mask;
     }
     return invalid_coord();
 }
@@ -180,6 +189,27 @@ __device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, bool le
     return v;
 }
 
+// The same window when the anchor sits on the first or last k-mer of its contig
+// (every in-loop step of _filter_targets_to_left/right, _mapper.pyx:229-246 and
+// :285-308, moves it there): the contig's first 8 bases are the top 16 bits of
+// first_kmer and its last 8 the low 16 bits of last_kmer, so the record that
+// was fetched for the move already holds the window and the pool is not
+// touched.  skm_index_create checks first_kmer/last_kmer against the pooled
+// bases; an index where they disagree takes the pool path (edge_windows = 0).
+template <bool STATS>
+__device__ __forceinline__ uint32_t contig8_edge(const DevIndex &ix, Coord c, bool leading, LaneStats *st)
+{
+    if (!ix.edge_windows) return contig8<STATS>(ix, c, leading, st);
+    const int32_t index = c.entry < 0 ? ~c.entry : c.entry;
+    if (STATS) { st->contig_reads++; st->seq_fetches++; }
+    const bool forward = c.entry >= 0;
+    uint32_t v;
+    if (forward == leading) v = (uint32_t)(ix.contigs[index].first_kmer >> (2 * K - 16)) & 0xffffu;
+    else v = (uint32_t)ix.contigs[index].last_kmer & 0xffffu;
+    if (!forward) v = revcomp8(v);
+    return v;
+}
+
 // KMerIndex.get_tail_kmer, _common.pyx:241-266
 template <bool STATS>
 __device__ __forceinline__ uint64_t tail_kmer(const DevIndex &ix, Coord c, LaneStats *st)
@@ -213,6 +243,11 @@ __device__ __forceinline__ ReadView read_view(const uint32_t *records, int recor
 __device__ __forceinline__ uint64_t read_kmer(const ReadView &r, int p)      // _kmer.pxd:46-68
 {
     return packed_window(r.codes, p) >> (64 - 2 * K);
+}
+// the 16 codes of aligned half word h (bases 16h .. 16h+15), first base on top
+__device__ __forceinline__ uint32_t read_half(const ReadView &r, int h)
+{
+    return reinterpret_cast<const uint32_t *>(r.codes)[h ^ 1];
 }
 __device__ __forceinline__ uint32_t read_code(const ReadView &r, int p)
 {

@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,14 @@ inline void strip(const char *&p, size_t &n)
 
 }  // namespace
 
+// The four arrays of one batch.  Slabs are recycled: touching fresh pages is
+// what a large batch costs most (measured here: 0.27 GB/s of first-touch
+// against 3 GB/s of parsing), so a reader keeps the slabs it has grown.
+struct skm_fastq_slab {
+    std::vector<char> bases, names;
+    std::vector<int64_t> offsets, name_offsets;
+};
+
 struct skm_fastq {
     std::vector<std::string> paths;
     bool paired = false;
@@ -83,16 +92,27 @@ struct skm_fastq {
     int64_t line_no = 0;
     bool finished = false;
     // current batch
-    std::vector<char> bases, names;
-    std::vector<int64_t> offsets, name_offsets;
+    skm_fastq_slab *cur = nullptr;
+    std::vector<skm_fastq_slab *> spare;      // under spare_lock: recycled from other threads
+    std::mutex spare_lock;
     int64_t held = 0;
     std::string s1, s2;
 
     void reset_batch()
     {
-        bases.clear(); names.clear();
-        offsets.assign(1, 0); name_offsets.assign(1, 0);
+        if (!cur) {
+            std::lock_guard<std::mutex> hold(spare_lock);
+            if (!spare.empty()) { cur = spare.back(); spare.pop_back(); }
+        }
+        if (!cur) cur = new skm_fastq_slab();
+        cur->bases.clear(); cur->names.clear();
+        cur->offsets.assign(1, 0); cur->name_offsets.assign(1, 0);
         held = 0;
+    }
+    ~skm_fastq()
+    {
+        delete cur;
+        for (skm_fastq_slab *s : spare) delete s;
     }
 };
 
@@ -116,6 +136,7 @@ extern "C" int skm_fastq_next(skm_fastq *q, int64_t *n_units, const char **bases
 {
     if (!q || !n_units) return SKM_ERR_ARG;
     q->reset_batch();
+    skm_fastq_slab *const b = q->cur;
     bool full = false;
     while (!full && !q->finished) {
         if (!q->open) {
@@ -141,30 +162,49 @@ extern "C" int skm_fastq_next(skm_fastq *q, int64_t *n_units, const char **bases
         if (phase == 0) {
             strip(l1, n1);
             if (n1) { ++l1; --n1; }                              // strip()[1:]
-            q->names.insert(q->names.end(), l1, l1 + n1);
-            q->name_offsets.push_back((int64_t)q->names.size());
+            b->names.insert(b->names.end(), l1, l1 + n1);
+            b->name_offsets.push_back((int64_t)b->names.size());
             q->held++;
         } else if (phase == 1) {
             strip(l1, n1);
-            q->bases.insert(q->bases.end(), l1, l1 + n1);
-            q->offsets.push_back((int64_t)q->bases.size());
+            b->bases.insert(b->bases.end(), l1, l1 + n1);
+            b->offsets.push_back((int64_t)b->bases.size());
             if (q->paired) {
                 strip(l2, n2);
-                q->bases.insert(q->bases.end(), l2, l2 + n2);
-                q->offsets.push_back((int64_t)q->bases.size());
+                b->bases.insert(b->bases.end(), l2, l2 + n2);
+                b->offsets.push_back((int64_t)b->bases.size());
             }
             if (q->held >= q->batch_units) full = true;          // len(read_names) >= BUFFER_SIZE
         }
     }
     // `if reads:` -- a trailing name without bases is dropped, as in the reference
-    const int64_t reads = (int64_t)q->offsets.size() - 1;
+    const int64_t reads = (int64_t)b->offsets.size() - 1;
     if (reads == 0) { *n_units = 0; q->held = 0; }
     else *n_units = q->held;
-    q->bases.push_back(0);
-    if (bases) *bases = q->bases.data();
-    if (offsets) *offsets = q->offsets.data();
-    if (names) *names = q->names.data();
-    if (name_offsets) *name_offsets = q->name_offsets.data();
+    b->bases.push_back(0);
+    if (bases) *bases = b->bases.data();
+    if (offsets) *offsets = b->offsets.data();
+    if (names) *names = b->names.data();
+    if (name_offsets) *name_offsets = b->name_offsets.data();
+    return SKM_OK;
+}
+
+extern "C" int skm_fastq_detach(skm_fastq *q, skm_fastq_slab **slab)
+{
+    if (!q || !slab || !q->cur) return SKM_ERR_ARG;
+    *slab = q->cur;              // the pointers of the last skm_fastq_next stay valid
+    q->cur = nullptr;
+    return SKM_OK;
+}
+
+extern "C" int skm_fastq_recycle(skm_fastq *q, skm_fastq_slab *slab)
+{
+    if (!slab) return SKM_OK;
+    if (q) {
+        std::lock_guard<std::mutex> hold(q->spare_lock);
+        if (q->spare.size() < 64) { q->spare.push_back(slab); return SKM_OK; }
+    }
+    delete slab;
     return SKM_OK;
 }
 

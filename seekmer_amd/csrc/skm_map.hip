@@ -135,7 +135,7 @@ struct TSet {
     __device__ __forceinline__ void set_word(int w, uint64_t v) { if (w == 0) word0 = v; else ext[w - 1] = v; }
     __device__ __forceinline__ int32_t entry(const DevIndex &ix, int i) const
     {
-        return forward ? ix.targets[start + i].entry : ~ix.targets[start + length - 1 - i].entry;
+        return forward ? ix.targets[start + i] : ~ix.targets[start + length - 1 - i];
     }
 };
 
@@ -195,7 +195,7 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
             const int32_t target_entry = set.entry(ix, 64 * w + bit);
             int32_t index_entry = 0;
             while (track != bound) {                 // skip index entries below the list entry
-                index_entry = ix.targets[track].entry;
+                index_entry = ix.targets[track];
                 if (!forward) index_entry = ~index_entry;
                 if (index_entry >= target_entry) break;
                 track += step;
@@ -412,9 +412,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
     __shared__ uint32_t fld_lds[FLD_WINDOW];
     // contexts, structure of arrays
     __shared__ int32_t c_state[NCTX], c_unit[NCTX], c_begin[NCTX], c_end[NCTX], c_aentry[NCTX],
-                       c_aoffset[NCTX], c_n[NCTX], c_scan[NCTX], c_len[NCTX], c_tstart[NCTX],
-                       c_tlen[NCTX];
-    __shared__ uint32_t c_kmer_lo[NCTX], c_kmer_hi[NCTX], c_mask_lo[NCTX], c_mask_hi[NCTX];
+                       c_aoffset[NCTX], c_scan[NCTX], c_len[NCTX], c_tstart[NCTX], c_tlen[NCTX];
+    // c_look: the 16 read bases (2-bit codes) of the aligned half word that holds base c_scan,
+    // so that rolling the first k-mer forward touches the read record once per 16 bases
+    __shared__ uint32_t c_kmer_lo[NCTX], c_kmer_hi[NCTX], c_mask_lo[NCTX], c_mask_hi[NCTX], c_look[NCTX];
     // one MPMC ring per action: entry = context | 0x8000 once written, 0 while empty
     __shared__ uint16_t ring[N_ACTIONS][NCTX];
     __shared__ uint32_t q_head[N_ACTIONS], q_tail[N_ACTIONS], next_unit, done_units, busy, stalled;
@@ -508,7 +509,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
             int word = valid ? c_state[c] : ST_IDLE;
             int state = word & 0xff, mate = (word >> 8) & 1, attempt = (word >> 9) & 1;
             const int64_t u = block_first + c_unit[c];
-            Span span{c_begin[c], c_end[c], Coord{c_aentry[c], c_aoffset[c]}, c_n[c]};
+            Span span{c_begin[c], c_end[c], Coord{c_aentry[c], c_aoffset[c]}, (int32_t)((uint32_t)word >> 10)};
+            uint32_t look = c_look[c];
             int scan_i = c_scan[c];
             uint64_t kmer = ((uint64_t)c_kmer_hi[c] << 32) | c_kmer_lo[c];
             uint64_t *const ext1 = ws_block + (size_t)c * 4 * (size_t)ext_words;
@@ -517,6 +519,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                      ((uint64_t)c_mask_hi[c] << 32) | c_mask_lo[c], mate ? ext2 : ext1, ext_words};
             ReadView rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u + mate : u);
             rv.len = c_len[c];          // (kept with the context: saves touching the record)
+            bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
             if (valid && action == A_START) {
                 rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u : u);
@@ -529,6 +532,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 } else {
                     kmer = read_kmer(rv, 0);
                     scan_i = K;
+                    look = read_half(rv, scan_i >> 4);
                     state = Y_FIRST;
                 }
             } else if (valid && action == A_LOOKUP) {
@@ -541,9 +545,11 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         span.end = span.begin;
                         map_contig<STATS>(ix, pos, set, span, &ls);
                         state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+                        anchored = true;
                     } else if (scan_i < rv.len) {
-                        kmer = ((kmer << 2) | read_code(rv, scan_i)) & KMER_MASK;     // _kmer.append
+                        kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;   // _kmer.append
                         ++scan_i;
+                        if ((scan_i & 15) == 0 && scan_i < rv.len) look = read_half(rv, scan_i >> 4);
                     } else {
                         state = N_MATE_DONE;                  // no hit: returned as is, no retry
                     }
@@ -585,7 +591,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     span.anchor.offset -= forward ? span.begin : -span.begin;
                     at = 0;
                 }
-                const int shift = sift4_left(contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
+                const int shift = sift4_left(in_loop ? contig8_edge<STATS>(ix, span.anchor, true, &ls)
+                                                     : contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
                 if (!in_loop) {
                     if (shift == INVALID_SHIFT) span.n = 0;
                     state = N_RIGHT_ENTER;
@@ -619,7 +626,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     span.anchor.offset += forward ? rest : -rest;
                     at = rv.len - ALIGN_LENGTH;
                 }
-                const int shift = sift4_right(contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
+                const int shift = sift4_right(in_loop ? contig8_edge<STATS>(ix, span.anchor, false, &ls)
+                                                      : contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
                 if (!in_loop) {
                     if (shift == INVALID_SHIFT) span.n = 0;
                     state = N_AFTER;
@@ -737,8 +745,15 @@ map_units_kernel(DevIndex ix, MapBatch b)
             while (valid && action != A_EMIT && state >= N_RIGHT_ENTER && state <= N_MATE_DONE) {
                 if (state == N_RIGHT_ENTER) {                 // map_read, :174-176 / :190-192
                     if (span.n != 0 && span.end < rv.len - K) {
-                        kmer = read_kmer(rv, span.end);
-                        state = Y_RA;
+                        // :283-284 re-anchors on the k-mer at span.end.  Straight after the
+                        // first hit that is the k-mer just looked up and the anchor is its
+                        // result, so the repeat is skipped (the counting build performs it).
+                        if (anchored && !STATS) {
+                            state = N_RIGHT;
+                        } else {
+                            kmer = read_kmer(rv, span.end);
+                            state = Y_RA;
+                        }
                     } else {
                         state = N_AFTER;
                     }
@@ -753,6 +768,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         span.end = span.begin;
                         kmer = read_kmer(rv, span.begin);
                         scan_i = span.begin + K;
+                        if (scan_i < rv.len) look = read_half(rv, scan_i >> 4);
                         state = Y_FIRST;
                     }
                 } else if (b.paired && mate == 0) {           // N_MATE_DONE: on to mate 2
@@ -770,6 +786,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     if (rv.len >= K) {
                         kmer = read_kmer(rv, 0);
                         scan_i = K;
+                        look = read_half(rv, scan_i >> 4);
                         state = Y_FIRST;
                     } else {
                         state = ST_UNIT_DONE;                 // mate 2 shorter than k: unmapped
@@ -781,12 +798,13 @@ map_units_kernel(DevIndex ix, MapBatch b)
 
             // store the context
             if (valid && action != A_EMIT) {
-                c_state[c] = state | (mate << 8) | (attempt << 9);
+                c_state[c] = (int32_t)((uint32_t)state | ((uint32_t)mate << 8) | ((uint32_t)attempt << 9)
+                                       | ((uint32_t)span.n << 10));
                 c_begin[c] = span.begin;
                 c_end[c] = span.end;
                 c_aentry[c] = span.anchor.entry;
                 c_aoffset[c] = span.anchor.offset;
-                c_n[c] = span.n;
+                c_look[c] = look;
                 c_scan[c] = scan_i;
                 c_len[c] = rv.len;
                 c_kmer_lo[c] = (uint32_t)kmer;

@@ -114,6 +114,33 @@ def test_chr21_adversarial(oracle, native_libs, chr21, chr21_oracle_index, paire
     _compare_tables(oracle, expected, fld, result)
 
 
+def test_edge_windows_and_pool_fallback(oracle, native_libs, chr21, chr21_oracle_index):
+    """A built index takes the 8-base windows at contig ends from first_kmer/last_kmer
+    (skm_index_info[6] == 1); an index whose edge k-mers do not spell the pooled bases
+    must fall back to the pool and still follow the reference's arithmetic
+    (get_tail_kmer reads the row, get_contig_sequence the pool, _common.pyx:103-137,
+    241-266)."""
+    rng = np.random.default_rng(23)
+    reads = _adversarial_reads(chr21[1], rng, 4000, 100)
+    bases, offsets = oracle.pack_reads(reads)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    assert index.device_info()['edge_windows'] == 1
+    contigs = chr21_oracle_index.contigs.copy()
+    names = contigs.dtype.names
+    first, last = names[2], names[3]
+    contigs[first][::3] ^= np.uint64(0x155)           # low bases of every third first_kmer
+    contigs[last][1::3] ^= np.uint64(0x2AA) << np.uint64(34)
+    tampered = oracle.OracleIndex(chr21_oracle_index.kmers, contigs, chr21_oracle_index.sequences,
+                                  chr21_oracle_index.targets, lengths=chr21_oracle_index.lengths)
+    t_index = make_product_index(tampered, chr21[0])
+    assert t_index.device_info()['edge_windows'] == 0
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(tampered, bases, offsets, len(reads) // 2, True, fld)
+    result, units = _run_gpu(t_index, bases, offsets, len(reads) // 2, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_config1_synthetic(oracle, native_libs):
     """BASELINE.json configs[0]: 1k-transcript synthetic index, 100k 2x75 pairs."""
     from seekmer_amd import synth, index_builder, infer
