@@ -75,7 +75,8 @@ int skm_index_destroy(skm_index *index);
 /* info[0]=n_slots [1]=n_contigs [2]=n_bases [3]=n_targets [4]=max target_count
  * [5]=device bytes held [6]=1 when every contig's first_kmer/last_kmer spell
  * its first/last k pooled bases (the mapper then takes 8-base windows at contig
- * ends from the contig row instead of the pool) [7]=reserved */
+ * ends from the contig row instead of the pool) [7]=1 when every contig's target
+ * slice ascends by signed entry (short list merges then run on registers) */
 int skm_index_info(const skm_index *index, int64_t info[8]);
 
 /* ------------------------------------------------------------------ mapper

@@ -37,6 +37,9 @@ def main():
     bases, offsets = synth.reads(1, pool, tx_offsets, 0, args.pairs, args.read_len, paired)
     hip = _native.hip()
     index.device_handle(0)
+    lengths = index.contigs['target_count'] if 'target_count' in index.contigs.dtype.names else index.contigs[index.contigs.dtype.names[-1]]
+    print('device index', index.device_info(), 'contig slices > 16 targets: %.4f, > 8: %.4f, max %d' % (
+        float((lengths > 16).mean()), float((lengths > 8).mean()), int(lengths.max())), flush=True)
     d_bases, d_off = ctypes.c_void_p(), ctypes.c_void_p()
     _native.check(hip.skm_device_malloc(0, bases.size, ctypes.byref(d_bases)))
     _native.check(hip.skm_device_malloc(0, offsets.size * 8, ctypes.byref(d_off)))
@@ -58,6 +61,10 @@ def main():
             (after['class_ns'] - before['class_ns']) * 1e-6, result.sizes()), flush=True)
     if args.stats:
         print(result.access_stats())
+    counts = np.sort(result.export()[2])[::-1]
+    print('class counts: top10 %s, top-100 share %.3f, top-1000 share %.3f, singletons %d' % (
+        counts[:10].tolist(), counts[:100].sum() / counts.sum(), counts[:1000].sum() / counts.sum(),
+        int((counts == 1).sum())))
 
 
 if __name__ == '__main__':

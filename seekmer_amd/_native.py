@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, 'libseekmer_hip.so')
+HIP_LIB_PATH = os.environ.get('SKM_HIP_LIB') or os.path.join(_HERE, 'libseekmer_hip.so')   # (override: tuning builds)
 HOST_LIB_PATH = os.path.join(_HERE, 'libseekmer_host.so')
 
 SKM_OK = 0

@@ -76,7 +76,7 @@ class KMerIndex:
         info = (ctypes.c_int64 * 8)()
         _native.check(_native.hip().skm_index_info(self.device_handle(device), info))
         names = ('n_slots', 'n_contigs', 'n_bases', 'n_targets', 'max_target_count', 'device_bytes',
-                 'edge_windows')
+                 'edge_windows', 'sorted_targets')
         return dict(zip(names, info))
 
     def release(self):

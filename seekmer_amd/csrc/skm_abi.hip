@@ -100,7 +100,6 @@ struct skm_mapper {
     // class table
     ClassTable t{};
     DBuf<ClassSlot> slots;
-    DBuf<int32_t> arena_len;
     DBuf<int32_t> arena;
     DBuf<int64_t> class_list;
     DBuf<unsigned long long> counters;   // [0]=arena_cursor [1]=n_classes [2]=n_unaligned [3]=n_units [8..2007]=fld
@@ -283,6 +282,15 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                              || encode(hc[c].offset + hc[c].length - K) != hc[c].last_kmer))
             edge_windows = false;
     }
+    bool sorted_targets = true;      // (the builder sorts (contig, entry, offset), _index_builder.pyx)
+    {
+        const Coord *ht = (const Coord *)targets;
+        for (int64_t c = 0; c < n_contigs && sorted_targets; ++c) {
+            const int64_t first = hc[c].target_offset, end = first + hc[c].target_length;
+            for (int64_t t = first + 1; t < end; ++t)
+                if (ht[t - 1].entry > ht[t].entry) { sorted_targets = false; break; }
+        }
+    }
     if (max_tc >= (1LL << 22))
         return fail(SKM_ERR_ARG, "a contig lists %lld targets (limit 4194303)", (long long)max_tc);
     const IndexEntry *hk = (const IndexEntry *)kmers;
@@ -337,6 +345,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     ix->d.n_targets = n_targets;
     ix->d.max_target_count = (int32_t)std::max<int64_t>(max_tc, 1);
     ix->d.edge_windows = edge_windows ? 1 : 0;
+    ix->d.sorted_targets = sorted_targets ? 1 : 0;
     ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(DevContig)
                 + n_targets * (int64_t)sizeof(int32_t) + n_words * 8;
     *out = ix;
@@ -362,7 +371,7 @@ extern "C" int skm_index_info(const skm_index *ix, int64_t info[8])
     info[4] = ix->d.max_target_count;
     info[5] = ix->bytes;
     info[6] = ix->d.edge_windows;
-    info[7] = 0;
+    info[7] = ix->d.sorted_targets;
     return SKM_OK;
 }
 
@@ -379,7 +388,6 @@ void bind_table(skm_mapper *m, uint64_t n_slots)
     m->t.slots = m->slots.p;
     m->t.slot_mask = n_slots - 1;
     m->t.arena = m->arena.p;
-    m->t.arena_len = m->arena_len.p;
     m->t.arena_capacity = (int64_t)m->arena.cap;
     m->t.arena_cursor = m->counters.p + CTR_ARENA;
     m->t.n_classes = m->counters.p + CTR_CLASSES;
@@ -396,7 +404,6 @@ void bind_table(skm_mapper *m, uint64_t n_slots)
 int table_reset(skm_mapper *m, uint64_t n_slots)
 {
     SKM_TRY(m->slots.ensure(n_slots));
-    SKM_TRY(m->arena_len.ensure(n_slots));
     SKM_TRY(m->arena.ensure(1 << 20));
     SKM_TRY(m->class_list.ensure(1 << 16));
     SKM_TRY(m->counters.ensure(CTR_WORDS));
@@ -422,14 +429,11 @@ int table_grow(skm_mapper *m, uint64_t want_slots, int64_t units_in_flight)
     while (need < want_slots) need <<= 1;
     if (need == n_slots) return SKM_OK;
     DBuf<ClassSlot> new_slots;
-    DBuf<int32_t> new_len;
     DBuf<int64_t> forward;
     SKM_TRY(new_slots.ensure(need));
-    SKM_TRY(new_len.ensure(need));
     SKM_TRY(forward.ensure(n_slots));
     ClassTable to = m->t;
     to.slots = new_slots.p;
-    to.arena_len = new_len.p;
     to.slot_mask = need - 1;
     launch_class_init(to, m->stream);
     launch_class_rehash(m->t, to, forward.p, m->stream);
@@ -441,10 +445,8 @@ int table_grow(skm_mapper *m, uint64_t want_slots, int64_t units_in_flight)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     m->slots.release();
-    m->arena_len.release();
     forward.release();
     m->slots = new_slots;
-    m->arena_len = new_len;
     bind_table(m, need);
     return SKM_OK;
 }
@@ -503,14 +505,14 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     // (~38 KB -> 4 blocks per CU); fewer blocks when the per-context list workspace
     // (2 lists of max_target_count entries) would not fit the budget
     constexpr int64_t CONTEXTS = 512;
-    int64_t blocks = std::min<int64_t>((n_units + CONTEXTS - 1) / CONTEXTS, (int64_t)ix->cu_count * 4);
+    int64_t blocks = std::min<int64_t>((n_units + CONTEXTS - 1) / CONTEXTS, (int64_t)ix->cu_count * MAP_BLOCKS_PER_CU);
     // per context: mask extension words (live + staging, two mates) for slices > 64 targets
     const int64_t ext_words = std::max<int64_t>(0, (ix->d.max_target_count + 63) / 64 - 1);
     SKM_TRY(m->workspace.ensure((size_t)(blocks * CONTEXTS * 4 * ext_words * 2 + 16)));
     SKM_TRY(m->mate1.ensure((size_t)(blocks * CONTEXTS) * 48));
     m->grid_blocks = (int)blocks;
     // entry arena: ~8 ids per unit plus one 2048-id slice of slack per wave
-    SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * 4 * 2048 + 4096));
+    SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * (MAP_THREADS / 64) * 2048 + 4096));
 
     MapBatch b{};
     b.records = m->records.p;
@@ -634,7 +636,7 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     if (!m) return SKM_OK;
     (void)hipSetDevice(m->ix->device);
     (void)hipStreamSynchronize(m->stream);
-    m->slots.release(); m->arena_len.release(); m->arena.release(); m->class_list.release();
+    m->slots.release(); m->arena.release(); m->class_list.release();
     m->counters.release();
     m->error.release(); m->bases.release(); m->offsets.release(); m->records.release();
     m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();

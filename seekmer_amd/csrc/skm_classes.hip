@@ -26,30 +26,36 @@ namespace skm {
 __device__ __forceinline__ uint32_t unsigned_id(int32_t e) { return (uint32_t)(e < 0 ? ~e : e); }
 
 __global__ void __launch_bounds__(256)
-class_init_kernel(ClassSlot *slots, int32_t *arena_len, uint64_t n_slots)
+class_init_kernel(ClassSlot *slots, uint64_t n_slots)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_slots;
          i += (uint64_t)gridDim.x * blockDim.x) {
         slots[i].key = 0;
         slots[i].count = 0;
         slots[i].first_seen = ~0ULL;
-        slots[i].arena_offset = -1;
-        arena_len[i] = 0;
+        slots[i].tuple = -1;
     }
 }
 
 // find-or-claim the slot whose tag is `key`; returns the slot index, or ~0
 // when `limit` probes did not reach the key or a free slot (table too full:
 // the host grows it and retries the deferred units)
+// `seen` returns the slot's first_seen as read on the way (possibly stale, i.e. too
+// large: it only ever decreases).  The probe reads are plain loads: a key never
+// changes once set, and a stale "empty" only costs the CAS that then reports the
+// real key -- device-scope atomics are served at the memory side of the fabric
+// (the XCDs' L2s are not coherent), so every one avoided is a fabric request less.
 __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned long long key,
-                                                bool &claimed, uint64_t limit)
+                                                bool &claimed, uint64_t limit,
+                                                unsigned long long *seen = nullptr)
 {
     uint64_t slot = key & t.slot_mask;
     claimed = false;
     if (limit > t.slot_mask + 1) limit = t.slot_mask + 1;
     for (uint64_t n = 0; n < limit; ++n) {
-        unsigned long long cur = __hip_atomic_load(&t.slots[slot].key, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
+        const ClassSlot *s = &t.slots[slot];
+        unsigned long long cur = s->key;
+        if (seen) *seen = s->first_seen;
         if (cur == 0) {
             cur = atomicCAS(&t.slots[slot].key, 0ULL, key);
             if (cur == 0) { claimed = true; return slot; }
@@ -70,19 +76,24 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
         if (retry_deferred && unit_slot[u] != -2) continue;
         const unsigned long long key = b.unit_key[u];
         if (key == 0) {                       // empty tuple = unaligned, mapper.py:87
-            atomicAdd(t.n_unaligned, 1ULL);
+            // one atomic per wave: same-address atomics serialise at one L2 channel
+            const unsigned long long peers = __ballot(1);
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(peers))
+                atomicAdd(t.n_unaligned, (unsigned long long)__popcll(peers));
             unit_slot[u] = -1;
             continue;
         }
         bool claimed;
-        const uint64_t slot = probe_claim(t, key, claimed, CLASS_PROBE_LIMIT);
+        unsigned long long seen = ~0ULL;
+        const uint64_t slot = probe_claim(t, key, claimed, CLASS_PROBE_LIMIT, &seen);
         if (slot == ~0ULL) {                  // deferred: counted after the table has grown
             atomicAdd(t.n_deferred, 1ULL);
             unit_slot[u] = -2;
             continue;
         }
         atomicAdd(&t.slots[slot].count, 1ULL);
-        atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
+        if (claimed || seen > (unsigned long long)(unit_base + u))
+            atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
         unit_slot[u] = (int64_t)slot;
         // the creator of a class stores its tuple later (class_commit_kernel): one class
         // (bits 40+) and n arena ids (bits 0-39), placed by a device-wide prefix sum
@@ -113,8 +124,7 @@ class_commit_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot,
         const int64_t slot = unit_slot[u];
         const int32_t *entries = b.unit_entries + b.unit_offset[u];
         for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(entries[i]);
-        t.arena_len[slot] = n;
-        t.slots[slot].arena_offset = off;
+        t.slots[slot].tuple = tuple_pack(off, n);
         t.class_list[k] = slot;
     }
 }
@@ -144,11 +154,11 @@ class_verify_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot)
         const int64_t slot = unit_slot[u];
         if (slot < 0) continue;
         const int n = b.unit_count[u];
-        const long long stored = t.slots[slot].arena_offset;
-        bool same = stored >= 0 && t.arena_len[slot] == n;
+        const long long stored = t.slots[slot].tuple;
+        bool same = stored >= 0 && tuple_len(stored) == n;
         if (same) {
             const int32_t *mine = b.unit_entries + b.unit_offset[u];
-            const int32_t *ref = t.arena + stored;
+            const int32_t *ref = t.arena + tuple_offset(stored);
             for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
         }
         if (!same) atomicExch(t.error, SKM_ERR_COLLISION);
@@ -170,8 +180,7 @@ class_rehash_kernel(ClassTable from, ClassTable to, int64_t *forward)
         if (slot == ~0ULL || !claimed) { atomicExch(to.error, SKM_ERR_STATE); forward[i] = -1; continue; }
         to.slots[slot].count = s.count;
         to.slots[slot].first_seen = s.first_seen;
-        to.slots[slot].arena_offset = s.arena_offset;
-        to.arena_len[slot] = from.arena_len[i];
+        to.slots[slot].tuple = s.tuple;
         forward[i] = (int64_t)slot;
     }
 }
@@ -194,8 +203,8 @@ class_compact_kernel(ClassTable t, int64_t n_classes, int64_t *cls_offset, int64
          k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t.class_list[k];
         const ClassSlot s = t.slots[i];
-        cls_offset[k] = s.arena_offset;
-        cls_len[k] = t.arena_len[i];
+        cls_offset[k] = s.tuple < 0 ? -1 : tuple_offset(s.tuple);
+        cls_len[k] = s.tuple < 0 ? 0 : tuple_len(s.tuple);
         cls_count[k] = (double)s.count;
         if (cls_first_seen) cls_first_seen[k] = s.first_seen;
     }
@@ -229,14 +238,14 @@ class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets
                 continue;
             }
             for (int i = 0; i < n; ++i) t.arena[a + i] = class_targets[off + i];
-            t.arena_len[slot] = n;
-            t.slots[slot].arena_offset = a;
+            t.slots[slot].tuple = tuple_pack(a, n);
             t.class_list[k] = (int64_t)slot;
             atomicAdd(t.n_classes, 1ULL);
         } else {
             // classes of the resident table are all committed between batches
-            const long long a = t.slots[slot].arena_offset;
-            bool same = a >= 0 && t.arena_len[slot] == n;
+            const long long stored = t.slots[slot].tuple;
+            bool same = stored >= 0 && tuple_len(stored) == n;
+            const long long a = tuple_offset(stored);
             for (int i = 0; same && i < n; ++i) same = t.arena[a + i] == class_targets[off + i];
             if (!same) { atomicExch(t.error, SKM_ERR_COLLISION); continue; }
         }
@@ -256,7 +265,7 @@ static inline unsigned grid_for(int64_t n)
 void launch_class_init(const ClassTable &t, hipStream_t stream)
 {
     hipLaunchKernelGGL(class_init_kernel, dim3(grid_for((int64_t)t.slot_mask + 1)), dim3(256), 0,
-                       stream, t.slots, t.arena_len, t.slot_mask + 1);
+                       stream, t.slots, t.slot_mask + 1);
 }
 
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,

@@ -52,6 +52,7 @@ struct DevIndex {
     int64_t n_targets;
     int32_t max_target_count;
     int32_t edge_windows;      // first_kmer/last_kmer agree with the pooled bases on every contig
+    int32_t sorted_targets;    // every contig's target slice ascends by signed entry (built indices do)
 };
 
 __device__ __forceinline__ Coord invalid_coord() { return Coord{0, -1}; }  // _coordinate.pxd:13-24

@@ -28,6 +28,17 @@ struct MapBatch {
     int32_t vote[8];              // quorum per action: start, lookup, merge, left, right, emit
 };
 
+// map kernel geometry: lanes per persistent block and the occupancy the register
+// allocator is asked to fit (waves per SIMD); 4 blocks per CU either way (LDS)
+#ifndef SKM_MAP_THREADS
+#define SKM_MAP_THREADS 256
+#endif
+#ifndef SKM_MAP_WAVES_PER_EU
+#define SKM_MAP_WAVES_PER_EU 4
+#endif
+constexpr int MAP_THREADS = SKM_MAP_THREADS;
+constexpr int MAP_BLOCKS_PER_CU = 4;
+
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
 void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream);
@@ -44,13 +55,16 @@ struct ClassSlot {                // 32 B
     unsigned long long key;       // 0 = empty
     unsigned long long count;
     unsigned long long first_seen;  // global unit index of the first unit of the class
-    long long arena_offset;       // -1 until the tuple has been committed to the arena
+    long long tuple;              // -1 until the tuple has been committed to the arena, then
+                                  // arena offset (bits 0-39) | tuple length (bits 40-62)
 };
+__host__ __device__ inline long long tuple_pack(long long offset, int n) { return offset | ((long long)n << 40); }
+__host__ __device__ inline long long tuple_offset(long long t) { return t & ((1LL << 40) - 1); }
+__host__ __device__ inline int tuple_len(long long t) { return (int)(t >> 40); }
 struct ClassTable {
     ClassSlot *slots;
     uint64_t slot_mask;
     int32_t *arena;               // committed tuples (unsigned ids)
-    int32_t *arena_len;           // per slot: tuple length (valid once committed)
     int64_t arena_capacity;
     unsigned long long *arena_cursor;
     unsigned long long *n_classes;

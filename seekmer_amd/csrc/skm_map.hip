@@ -166,6 +166,60 @@ __device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, TSet &se
     }
 }
 
+// ---- short lists in registers --------------------------------------------
+// The two-pointer walks below cost one dependent load per step and the wave
+// waits for its longest lane (measured: 44k cycles per emission round in
+// _intersect alone, 12k per index lookup round).  Every slice of a built index
+// is sorted by signed entry (the builder sorts (contig, entry, offset);
+// skm_index_create verifies it, DevIndex.sorted_targets), so both walks are
+// multiset intersections that keep the earliest duplicates of the left list --
+// and for slices of at most LIST_REGS targets that is computed on registers:
+// both lists are fetched with independent loads (one round trip) and compared
+// all-pairs with fully unrolled code.  Longer slices, unsorted indices and the
+// counting build take the walks.
+constexpr int LIST_REGS = 16;
+#ifdef SKM_STATS_LIST_FAST          // profiling aid: cycle census of the register paths (counters then undercount)
+#define LIST_FAST(stats) true
+#else
+#define LIST_FAST(stats) (!(stats))
+#endif
+constexpr int32_t NO_ENTRY = INT32_MIN;      // (would be transcript 2^31-1: cannot occur, n_targets < 2^31)
+
+// entries at list positions 0..15 of a slice of 1..16 targets; NO_ENTRY where
+// the position is outside the slice or cleared in `keep`
+__device__ __forceinline__ void load_list(const DevIndex &ix, int32_t start, int32_t length, bool forward,
+                                          uint32_t keep, int32_t (&e)[LIST_REGS])
+{
+    const int last = length - 1;
+#pragma unroll
+    for (int i = 0; i < LIST_REGS; ++i) {
+        const int p = min(i, last);
+        const int32_t raw = ix.targets[forward ? start + p : start + last - p];
+        e[i] = (i <= last && ((keep >> i) & 1u)) ? (forward ? raw : ~raw) : NO_ENTRY;
+    }
+}
+
+// positions of `a` (ascending, NO_ENTRY = absent) that a two-pointer walk against the
+// multiset `b` keeps: the r-th copy of a value survives iff b holds more than r copies
+__device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS])
+{
+    uint32_t keep = 0;
+    int32_t prev = NO_ENTRY;
+    int run = 0;
+#pragma unroll
+    for (int i = 0; i < LIST_REGS; ++i) {
+        const int32_t v = a[i];
+        int copies = 0;
+#pragma unroll
+        for (int j = 0; j < LIST_REGS; ++j) copies += (b[j] == v) ? 1 : 0;
+        const bool present = v != NO_ENTRY;
+        run = (present && v == prev) ? run + 1 : (present ? 0 : run);
+        if (present) prev = v;
+        if (present && run < copies) keep |= 1u << i;
+    }
+    return keep;
+}
+
 // KMerIndex._filter_on_contig, _common.pyx:185-235: two-pointer merge of the
 // list (ascending signed entries) with the anchor contig's slice; an empty
 // intersection leaves the list as it was and returns false.
@@ -179,6 +233,17 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
     const int32_t start = (int32_t)ix.contigs[contig].target_offset;
     const int32_t length = (int32_t)ix.contigs[contig].target_length;
     if (STATS) st->contig_reads++;
+    if (LIST_FAST(STATS) && ix.sorted_targets && set.length <= LIST_REGS && length <= LIST_REGS) {
+        if (length == 0) return false;
+        int32_t a[LIST_REGS], t[LIST_REGS];
+        load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, a);
+        load_list(ix, start, length, forward, 0xffffu, t);     // (order within the slice is immaterial)
+        const uint32_t keep = keep_common(a, t);
+        if (keep == 0) return false;
+        set.word0 = keep;
+        span.n = __builtin_popcount(keep);
+        return true;
+    }
     int track = forward ? start : start + length - 1;
     const int bound = forward ? start + length : start - 1;
     const int step = forward ? 1 : -1;
@@ -305,10 +370,24 @@ __device__ __forceinline__ int right_move(const DevIndex &ix, Coord a)
 
 // _intersect, _mapper.pyx:350-397: mate 1 ascending against mate 2 walked from
 // its end with complemented entries; matches are consumed one to one.
+template <bool STATS>
 __device__ __forceinline__ bool intersect(const DevIndex &ix, TSet &a, Span &s1, const TSet &b2, const Span &s2)
 {
     if (s1.n == 0) return true;
     if (s2.n == 0) return false;
+    if (LIST_FAST(STATS) && ix.sorted_targets && a.length <= LIST_REGS && b2.length <= LIST_REGS) {
+        int32_t e1[LIST_REGS], e2[LIST_REGS];
+        load_list(ix, a.start, a.length, a.forward, (uint32_t)a.word0, e1);
+        // mate 2 is compared complemented: ~entry(i).  load_list with the orientation flipped
+        // yields exactly that at mirrored positions, and positions do not matter on this side.
+        const uint32_t mirrored = __brev((uint32_t)b2.word0) >> (32 - b2.length);
+        load_list(ix, b2.start, b2.length, !b2.forward, mirrored, e2);
+        const uint32_t keep = keep_common(e1, e2);
+        a.word0 = keep;
+        if (keep == 0) return false;
+        s1.n = __builtin_popcount(keep);
+        return true;
+    }
     int w2 = b2.words() - 1;
     uint64_t m2 = b2.word(w2);
     // cursor over mate 2, highest list position first
@@ -406,7 +485,7 @@ __device__ __forceinline__ int action_of(int state)
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(MAP_THREADS, SKM_MAP_WAVES_PER_EU)
 map_units_kernel(DevIndex ix, MapBatch b)
 {
     __shared__ uint32_t fld_lds[FLD_WINDOW];
@@ -442,8 +521,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
     uint32_t census[1 + 2 * N_ACTIONS];
     for (int i = 0; i < 1 + 2 * N_ACTIONS; ++i) census[i] = 0;
     // cycle stamps (STATS build): [0]=idle / choosing [1]=unused [2..]=per action
-    unsigned long long cyc[2 + N_ACTIONS];
-    for (int i = 0; i < 2 + N_ACTIONS; ++i) cyc[i] = 0;
+    unsigned long long cyc[2 + N_ACTIONS + 6];      // [8..13]: phases of the emission
+    for (int i = 0; i < 2 + N_ACTIONS + 6; ++i) cyc[i] = 0;
     unsigned long long t_mark = STATS ? clock64() : 0;
 
     // seed: every context takes a unit and queues up for A_START
@@ -525,6 +604,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u : u);
                 mate = 0;
                 attempt = 0;
+                set.start = 0; set.length = 0; set.word0 = 0;   // (a context starts with whatever LDS held)
                 span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
                 if (STATS) { read_bases += rv.len; n_reads++; }
                 if (rv.len < K) {
@@ -647,6 +727,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 }
             } else if (action == A_EMIT) {
                 // ---------------------------------------------- A_EMIT: finished units
+                unsigned long long t_e = STATS ? clock64() : 0;
+                auto phase = [&](int k) {
+                    if (STATS) { const unsigned long long t = clock64(); cyc[8 + k] += t - t_e; t_e = t; }
+                };
                 int n_out = 0;
                 if (valid) {
                     if (b.paired) {
@@ -656,7 +740,9 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         TSet set1{m1.set_start, m1.set_length_fwd >> 1, (m1.set_length_fwd & 1) != 0,
                                   m1.word0, ext1, ext_words};
                         const Span s2 = span;
-                        if (!intersect(ix, set1, s1, set, s2)) {
+                        if (STATS) asm volatile("" ::"v"(m1.word0));
+                        phase(0);
+                        if (!intersect<STATS>(ix, set1, s1, set, s2)) {
                             s1.n = 0;
                             s1.begin = 0;
                             s1.end = -K;
@@ -671,6 +757,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         span = s1;
                         set = set1;
                     }
+                    phase(1);
                     // fragment length rule, _mapper.pyx:90-94
                     int length = span.end - span.begin + K;
                     if (length > 0) {
@@ -680,6 +767,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     }
                     n_out = span.n;
                 }
+                phase(2);
                 // one slice of the entry arena for the whole chunk
                 int scan = n_out;
 #pragma unroll
@@ -695,12 +783,26 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     chunk_pos = (int64_t)__shfl(got, 0, 64);
                     chunk_end = chunk_pos + want;
                 }
+                phase(3);
                 if (valid) {
                     const int64_t off = chunk_pos + scan - n_out;
                     uint64_t key = 0x243F6A8885A308D3ULL ^ (uint64_t)n_out;
                     const bool fits = off + n_out <= b.ids_capacity;
                     int i = 0;
-                    const int words = n_out ? set.words() : 0;
+                    int words = n_out ? set.words() : 0;
+                    if (LIST_FAST(STATS) && n_out && set.length <= LIST_REGS) {      // short list: one round trip
+                        int32_t e[LIST_REGS];
+                        load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, e);
+#pragma unroll
+                        for (int k = 0; k < LIST_REGS; ++k) {
+                            if (e[k] != NO_ENTRY) {
+                                if (fits) b.unit_entries[off + i] = e[k];
+                                key = tuple_key_step(key, (uint32_t)(e[k] < 0 ? ~e[k] : e[k]));
+                                ++i;
+                            }
+                        }
+                        words = 0;
+                    }
                     for (int w = 0; w < words; ++w) {
                         uint64_t m = set.word(w);
                         while (m) {
@@ -712,6 +814,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         }
                     }
                     if (key == 0) key = 1;
+                    phase(4);
                     b.unit_offset[u] = off;
                     b.unit_count[u] = n_out;
                     b.unit_key[u] = n_out ? key : 0;
@@ -721,6 +824,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     if (STATS) tuple_ids += n_out;
                 }
                 chunk_pos += wave_total;
+                phase(5);
                 // each of these contexts takes the block's next unit, or retires
                 const unsigned long long finished = __ballot(valid);
                 uint32_t base = 0;
@@ -855,7 +959,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
         atomicAdd(&o[9], (unsigned long long)tuple_ids);
         if (lane == 0) {
             for (int i = 0; i < 1 + 2 * N_ACTIONS; ++i) atomicAdd(&o[16 + i], (unsigned long long)census[i]);
-            for (int i = 0; i < 2 + N_ACTIONS; ++i) atomicAdd(&o[32 + i], cyc[i]);
+            for (int i = 0; i < 2 + N_ACTIONS + 6; ++i) atomicAdd(&o[32 + i], cyc[i]);
         }
     }
 }
@@ -884,9 +988,9 @@ void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bo
 {
     if (b.n_units == 0) return;
     if (stats)
-        hipLaunchKernelGGL(map_units_kernel<true>, dim3(grid_blocks), dim3(256), 0, stream, ix, b);
+        hipLaunchKernelGGL(map_units_kernel<true>, dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
     else
-        hipLaunchKernelGGL(map_units_kernel<false>, dim3(grid_blocks), dim3(256), 0, stream, ix, b);
+        hipLaunchKernelGGL(map_units_kernel<false>, dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
 }
 
 }  // namespace skm

@@ -55,8 +55,8 @@ table_dump_kernel(ClassTable t, int64_t n_classes, int64_t *arena_off, int64_t *
          k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t.class_list[k];
         const ClassSlot s = t.slots[i];
-        arena_off[k] = s.arena_offset;
-        len[k] = t.arena_len[i];
+        arena_off[k] = s.tuple < 0 ? -1 : tuple_offset(s.tuple);
+        len[k] = s.tuple < 0 ? 0 : tuple_len(s.tuple);
         count[k] = (double)s.count;
         first_seen[k] = s.first_seen;
     }
