@@ -131,11 +131,13 @@ def main():
     state = {}
 
     stage = {}
-    profile_stages = os.environ.get('SKM_BENCH_PROFILE') == '1'
+    profile_stages = os.environ.get('SKM_BENCH_PROFILE') in ('1', '2')   # 2: host wall per call, no syncs
+    profile_sync = os.environ.get('SKM_BENCH_PROFILE') == '1'
 
     def mark(name, t0):
         if profile_stages:
-            _native.check(hip.skm_device_synchronize(device))
+            if profile_sync:
+                _native.check(hip.skm_device_synchronize(device))
             stage[name] = stage.get(name, 0.0) + time.perf_counter() - t0
         return time.perf_counter()
 
@@ -145,28 +147,15 @@ def main():
         t = mark('reset', t)
         result.map_resident(d_bases, d_offsets, n_units, True, args.read_len)
         t = mark('map_batch', t)
-        fld = result.fragment_length_counts
-        if world > 1:                      # MapResult.merge_fragment_lengths across ranks
-            import torch
-            t = torch.from_numpy(fld)
-            dist.all_reduce(t)
-        eff = result._effective_lengths(fld)
-        t = mark('fld+eff_len', t)
-        quant = infer._QuantHandle.from_map_result(result, n_tx)
-        t = mark('quant_setup', t)
-        try:
-            if comm:
-                _native.check(hip.skm_quant_set_comm(quant.handle, comm))
-            x = np.ones(n_tx, dtype='f8') / eff
-            x /= x.sum()
-            x, iters = quant.em(x, eff)
-            t = mark('em', t)
-            state['em'] = quant.timing()
-        finally:
-            quant.close()
-        t = mark('quant_close', t)
-        state['tpm'] = infer._tpm(x)
-        t = mark('tpm', t)
+        before = result.timing()
+        # fragment lengths (RCCL all-reduce over the ranks) -> effective lengths -> start
+        # vector -> EM -> TPM: one native call on the resident class table
+        tpm, iters = infer.quantify_resident(result, comm=comm if comm else None, return_iters=True)
+        t = mark('quantify', t)
+        after = result.timing()
+        state['em'] = {'em_ns': after['em_ns'] - before['em_ns'],
+                       'iterations': after['em_iterations'] - before['em_iterations']}
+        state['tpm'] = tpm
         state['iters'] = iters
 
     def barrier():

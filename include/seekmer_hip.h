@@ -128,7 +128,8 @@ int skm_mapper_clear(skm_mapper *mapper);           /* MapResult.clear, mapper.p
  * zeroed) while keeping every HBM buffer allocated. */
 int skm_mapper_reset(skm_mapper *mapper);
 /* stats[0]=pack kernel ns [1]=map kernel ns [2]=class kernels ns [3]=batches
- * [4]=units (HIP-event times accumulated over batches on the mapper stream) */
+ * [4]=units (HIP-event times accumulated over batches on the mapper stream)
+ * [5]=EM ns [6]=EM steps of the skm_quant_infer calls made on this mapper */
 int skm_mapper_timing(skm_mapper *mapper, double stats[8]);
 /* Access counters of the instrumented build of the map kernel (they define the
  * algorithmic bytes): enable, map, then read.  out[0]=reads
@@ -187,6 +188,15 @@ int skm_comm_unique_id(void *id128);                 /* rank 0: 128-byte id, sin
 int skm_comm_create(int device, const void *id128, int rank, int world, skm_comm **out);
 int skm_comm_destroy(skm_comm *comm);
 int skm_quant_set_comm(skm_quant *quant, skm_comm *comm);   /* NULL detaches */
+
+/* One sample, mapper table -> TPM, without leaving the device: MapResult.effective_lengths
+ * (seekmer/mapper.py:134-141, the histogram all-reduced over `comm`'s ranks when comm is
+ * not NULL) + quantify() (seekmer/infer.py:88-130: start vector 1/l normalised with
+ * numpy's sum, em(), TPM scaling).  lengths: host f8[n_tx] transcript lengths.  Host
+ * outputs (each may be NULL): tpm[n_tx], effective_lengths[n_tx], *iters. */
+int skm_quant_infer(skm_mapper *mapper, skm_comm *comm, const double *lengths, int64_t n_tx,
+                    double rel_tol, double x_floor, int64_t max_iters,
+                    double *tpm, double *effective_lengths, int64_t *iters);
 
 /* ============================ libseekmer_host.so ========================== */
 

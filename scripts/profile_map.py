@@ -23,6 +23,8 @@ def main():
     ap.add_argument('--single', action='store_true')
     ap.add_argument('--cache', default='')
     ap.add_argument('--stats', action='store_true')
+    ap.add_argument('--sorted', action='store_true',
+                    help='experiment: re-run with the units ordered by their anchor contig')
     args = ap.parse_args()
     t0 = time.time()
     ids, pool, tx_offsets = synth.transcriptome(1, args.genes)
@@ -61,6 +63,27 @@ def main():
             (after['class_ns'] - before['class_ns']) * 1e-6, result.sizes()), flush=True)
     if args.stats:
         print(result.access_stats())
+    if args.sorted:
+        rm = mapper.ReadMapper(index, result)
+        units = rm.last_batch(args.pairs)
+        entry = units[2].astype(np.int64)
+        contig = np.where(entry < 0, ~entry, entry)
+        none = units[4] == 0          # spread the unmapped units evenly (block ranges are static)
+        contig[none] = np.random.default_rng(1).integers(0, int(contig.max()) + 1, int(none.sum()))
+        order = np.argsort(contig, kind='stable')
+        width = 2 if paired else 1
+        reads2d = bases[:-1].reshape(args.pairs, width * args.read_len)[order]
+        sorted_bases = np.concatenate([reads2d.reshape(-1), np.zeros(1, np.uint8)])
+        _native.check(hip.skm_device_upload(0, d_bases, sorted_bases.ctypes.data, sorted_bases.size))
+        for rep in range(args.reps):
+            result.reset()
+            before = result.timing()
+            result.map_resident(d_bases, d_off, args.pairs, paired, args.read_len)
+            after = result.timing()
+            print('sorted rep %d: pack %.3f map %.3f classes %.3f ms sizes %s' % (
+                rep, (after['pack_ns'] - before['pack_ns']) * 1e-6,
+                (after['map_ns'] - before['map_ns']) * 1e-6,
+                (after['class_ns'] - before['class_ns']) * 1e-6, result.sizes()), flush=True)
     counts = np.sort(result.export()[2])[::-1]
     print('class counts: top10 %s, top-100 share %.3f, top-1000 share %.3f, singletons %d' % (
         counts[:10].tolist(), counts[:100].sum() / counts.sum(), counts[:1000].sum() / counts.sum(),

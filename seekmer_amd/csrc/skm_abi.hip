@@ -125,6 +125,7 @@ struct skm_mapper {
     int64_t host_classes = 0, host_arena_used = 0;
     bool want_stats = false;
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
+    double t_em_ns = 0, em_iters = 0;          // skm_quant_infer calls on this mapper
     unsigned long long stats_total[48] = {0};
     int vote[8] = {1, 1, 1, 1, 1, 1, 0, 0};   // quorum per action (start, lookup, merge, left, right, emit)
 };
@@ -877,7 +878,7 @@ extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
     std::lock_guard<std::mutex> lock(m->mu);
     stats[0] = m->t_pack_ns; stats[1] = m->t_map_ns; stats[2] = m->t_class_ns;
     stats[3] = m->batches; stats[4] = (double)m->units_done;
-    stats[5] = 0; stats[6] = 0; stats[7] = 0;
+    stats[5] = m->t_em_ns; stats[6] = m->em_iters; stats[7] = 0;
     return SKM_OK;
 }
 
@@ -931,9 +932,9 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     q->n_classes = n_classes;
     q->n_ids = n_ids;
     HIP_TRY(pool_stream_acquire(&q->stream));
-    for (auto &e : q->ev) HIP_TRY(hipEventCreate(&e));
-    for (auto &e : q->chunk_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void **)&q->pinned, 64 * sizeof(unsigned long long)));
+    for (auto &e : q->ev) HIP_TRY(pool_event_acquire(&e, true));
+    for (auto &e : q->chunk_ev) HIP_TRY(pool_event_acquire(&e, false));
+    HIP_TRY(pool_pinned_acquire((void **)&q->pinned));
     const size_t C = (size_t)std::max<int64_t>(n_classes, 1), M = (size_t)std::max<int64_t>(n_ids, 1);
     const size_t T = (size_t)std::max<int64_t>(n_tx, 1);
     const size_t R = (size_t)quant_rows_upper_bound(n_tx, n_ids);
@@ -1015,7 +1016,7 @@ int load_rccl()
     return SKM_OK;
 }
 
-constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;
+constexpr int NCCL_FLOAT64 = 8, NCCL_UINT64 = 5, NCCL_SUM = 0;
 
 #define NCCL_TRY(call)                                                                   \
     do {                                                                                 \
@@ -1174,6 +1175,75 @@ extern "C" int skm_quant_create_from_mapper(skm_mapper *m, int64_t n_tx, skm_qua
     return SKM_OK;
 }
 
+// One sample from the resident class table to TPM without leaving the device:
+// fragment-length histogram (all-reduced over the ranks of `comm`) -> effective
+// lengths (mapper.py:134-141) -> start vector 1/l normalised with numpy's sum
+// (infer.py:116-119) -> EM to the stop rule (:133-168) -> TPM scaling (:127-129).
+extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *lengths, int64_t n_tx,
+                               double rel_tol, double x_floor, int64_t max_iters,
+                               double *tpm, double *effective_lengths, int64_t *iters)
+{
+    if (!m || !lengths || n_tx <= 0) return fail(SKM_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (comm && comm->device != m->ix->device)
+        return fail(SKM_ERR_ARG, "communicator and mapper live on different GPUs");
+    SKM_TRY(set_device(m->ix->device));
+    const int64_t C = m->host_classes, M = m->host_arena_used;
+    skm_quant *q = new skm_quant();
+    int rc = quant_alloc(q, m->ix->device, n_tx, C, M);
+    if (rc != SKM_OK) { delete q; return rc; }
+    if (comm) { q->comm = comm->comm; q->rank = comm->rank; q->world = comm->world; }
+    DBuf<unsigned long long> fld;
+    DBuf<double> sums;
+    const int64_t n_blocks = (n_tx + 8191) / 8192;
+    auto body = [&]() -> int {
+        SKM_TRY(fld.ensure(MAX_FRAGMENT_LENGTH));
+        SKM_TRY(sums.ensure(n_blocks + 2));
+        double *const total = sums.p + n_blocks;          // [0] sum, [1] sum / divisor
+        unsigned long long ctr[4];
+        HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));   // (mapper stream is idle)
+        q->n_total = (double)(ctr[CTR_UNITS] - ctr[CTR_UNALIGNED]);
+        HIP_TRY(hipMemcpyAsync(fld.p, m->counters.p + CTR_FLD, MAX_FRAGMENT_LENGTH * 8,
+                               hipMemcpyDeviceToDevice, q->stream));
+        if (q->comm)                                       // merge_fragment_lengths over the ranks
+            NCCL_TRY(g_rccl.AllReduce(fld.p, fld.p, MAX_FRAGMENT_LENGTH, NCCL_UINT64, NCCL_SUM, q->comm,
+                                      q->stream));
+        HIP_TRY(hipMemcpyAsync(q->x1.p, lengths, n_tx * 8, hipMemcpyHostToDevice, q->stream));
+        launch_effective_lengths(fld.p, q->x1.p, n_tx, q->eff_len.p, q->stream);
+        if (effective_lengths)
+            HIP_TRY(hipMemcpyAsync(effective_lengths, q->eff_len.p, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
+        if (C == 0) {                                      // quantify(): no class -> zeros (infer.py:100-101)
+            HIP_TRY(hipStreamSynchronize(q->stream));
+            if (tpm) memset(tpm, 0, (size_t)n_tx * 8);
+            if (iters) *iters = 0;
+            return SKM_OK;
+        }
+        launch_reciprocal(q->eff_len.p, n_tx, q->x0.p, q->stream);
+        launch_np_sum(q->x0.p, n_tx, 1.0, sums.p, total, q->stream);
+        launch_divide(q->x0.p, n_tx, total, false, 0.0, q->stream);
+        SKM_TRY(quant_finish_setup(q, &m->t));
+        int64_t it = 0;
+        SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, &it));
+        m->t_em_ns += q->t_em_ns;
+        m->em_iters += (double)it;
+        double *const x = (it & 1) ? q->x1.p : q->x0.p;
+        launch_np_sum(x, n_tx, 1000000.0, sums.p, total, q->stream);
+        launch_divide(x, n_tx, total + 1, true, 0.001, q->stream);
+        launch_np_sum(x, n_tx, 1000000.0, sums.p, total, q->stream);
+        launch_divide(x, n_tx, total + 1, false, 0.0, q->stream);
+        HIP_TRY(hipGetLastError());
+        if (tpm) HIP_TRY(hipMemcpyAsync(tpm, x, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+        if (iters) *iters = it;
+        return SKM_OK;
+    };
+    rc = body();
+    fld.release();
+    sums.release();
+    skm_quant_destroy(q);
+    return rc;
+}
+
 extern "C" int skm_quant_destroy(skm_quant *q)
 {
     if (!q) return SKM_OK;
@@ -1184,9 +1254,9 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->inner.release(); q->row_sum.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
     q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
     q->cum.release(); q->draw.release();
-    for (auto &e : q->ev) (void)hipEventDestroy(e);
-    for (auto &e : q->chunk_ev) (void)hipEventDestroy(e);
-    if (q->pinned) (void)hipHostFree(q->pinned);
+    for (auto &e : q->ev) pool_event_release(e, true);
+    for (auto &e : q->chunk_ev) pool_event_release(e, false);
+    pool_pinned_release(q->pinned);
     pool_stream_release(q->stream);
     delete q;
     return SKM_OK;

@@ -320,6 +320,107 @@ void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream
     hipLaunchKernelGGL(em_decide_kernel, dim3(1), dim3(256), 0, stream, p, (int)blocks);
 }
 
+// ---- numpy.sum of a contiguous f8 array, bit for bit ----------------------
+// numpy adds the array up in blocks of 8192 elements (its reduction buffer),
+// block sums accumulated left to right, and each block with pairwise_sum:
+// below 8 elements a plain loop, up to 128 eight strided accumulators combined
+// as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the remainder in order, above
+// that a split at n/2 rounded down to a multiple of 8 (numpy/_core/src/umath/
+// loops_utils.h.src).  The start vector x /= x.sum() (seekmer/infer.py:118-119)
+// and the TPM scaling (:127-129) go through it, so doing them on the device
+// without it would move the EM input by an ulp.  One lane per block: 8192
+// dependent adds are ~40 us, and there are only T/8192 blocks.
+// (the recursion is spelled as a chain of distinct functions, one per level, so
+// that the call graph is static: 8192 elements split at most 7 times)
+template <int LEVELS>
+__device__ __attribute__((noinline)) double np_pairwise(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.0;                      // numpy starts from -0.0 + a[0]; same value for our data
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise<LEVELS - 1>(a, n2) + np_pairwise<LEVELS - 1>(a + n2, n - n2);
+}
+template <>
+__device__ __attribute__((noinline)) double np_pairwise<0>(const double *a, int n)
+{
+    double r = 0.0;                          // not reached for blocks of at most 8192 elements
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+}
+
+__global__ void __launch_bounds__(64)
+np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ block_sums)
+{
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t first = b * 8192;
+    if (first >= n) return;
+    block_sums[b] = np_pairwise<8>(a + first, (int)min((int64_t)8192, n - first));
+}
+
+// out[0] = the sum, out[1] = sum / divisor
+__global__ void np_sum_final_kernel(const double *block_sums, int64_t n_blocks, double divisor, double *out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double acc = 0.0;
+    for (int64_t b = 0; b < n_blocks; ++b) acc += block_sums[b];
+    out[0] = acc;
+    out[1] = acc / divisor;
+}
+
+__global__ void __launch_bounds__(256)
+reciprocal_kernel(const double *__restrict__ l, int64_t n, double *__restrict__ x)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) x[i] = 1.0 / l[i];
+}
+
+// x /= *s, then (TPM) x[x < floor] = 0
+__global__ void __launch_bounds__(256)
+divide_kernel(double *__restrict__ x, int64_t n, const double *__restrict__ s, bool threshold, double floor)
+{
+    const double d = *s;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double v = x[i] / d;
+        if (threshold && v < floor) v = 0.0;
+        x[i] = v;
+    }
+}
+
+void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sums, double *out,
+                   hipStream_t stream)
+{
+    const int64_t n_blocks = (n + 8191) / 8192;
+    if (n_blocks)
+        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, stream,
+                           a, n, block_sums);
+    hipLaunchKernelGGL(np_sum_final_kernel, dim3(1), dim3(1), 0, stream, block_sums, n_blocks, divisor, out);
+}
+
+void launch_reciprocal(const double *l, int64_t n, double *x, hipStream_t stream)
+{
+    hipLaunchKernelGGL(reciprocal_kernel, dim3(grid_for(n)), dim3(256), 0, stream, l, n, x);
+}
+
+void launch_divide(double *x, int64_t n, const double *s, bool threshold, double floor, hipStream_t stream)
+{
+    hipLaunchKernelGGL(divide_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, n, s, threshold, floor);
+}
+
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
                               double *out, hipStream_t stream)
 {

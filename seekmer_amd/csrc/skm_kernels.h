@@ -156,6 +156,11 @@ void launch_permute_f64(const double *x, const int32_t *perm, int64_t n, double 
                         hipStream_t stream);
 int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids);
 
+// numpy.sum(a) bit for bit -> out[0], out[1] = out[0] / divisor; block_sums: ceil(n/8192) doubles
+void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sums, double *out,
+                   hipStream_t stream);
+void launch_reciprocal(const double *l, int64_t n, double *x, hipStream_t stream);
+void launch_divide(double *x, int64_t n, const double *s, bool threshold, double floor, hipStream_t stream);
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
                               double *out, hipStream_t stream);
 void launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_t n_draws,

@@ -15,6 +15,8 @@ std::unordered_map<void *, Block> g_live;                       // handed out
 std::map<std::pair<int, size_t>, std::vector<void *>> g_parked; // by (device, size class)
 std::unordered_map<int, std::vector<hipStream_t>> g_streams;
 std::unordered_map<hipStream_t, int> g_stream_device;
+std::unordered_map<int, std::vector<hipEvent_t>> g_events[2];     // [timing]
+std::vector<void *> g_pinned;
 size_t g_parked_bytes = 0;
 constexpr size_t PARK_LIMIT = 48ULL << 30;                      // beyond this, free for real
 
@@ -119,6 +121,52 @@ hipError_t pool_stream_acquire(hipStream_t *out)
     std::lock_guard<std::mutex> lock(g_mu);
     g_stream_device[*out] = device;
     return hipSuccess;
+}
+
+hipError_t pool_event_acquire(hipEvent_t *out, bool timing)
+{
+    int device = 0;
+    hipError_t err = hipGetDevice(&device);
+    if (err != hipSuccess) return err;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto &v = g_events[timing ? 1 : 0][device];
+        if (!v.empty()) {
+            *out = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+
+void pool_event_release(hipEvent_t event, bool timing)
+{
+    if (!event) return;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipEventDestroy(event); return; }
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_events[timing ? 1 : 0][device].push_back(event);
+}
+
+hipError_t pool_pinned_acquire(void **out)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!g_pinned.empty()) {
+            *out = g_pinned.back();
+            g_pinned.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipHostMalloc(out, POOL_PINNED_BYTES);
+}
+
+void pool_pinned_release(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_pinned.push_back(p);
 }
 
 void pool_stream_release(hipStream_t stream)

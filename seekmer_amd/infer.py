@@ -17,7 +17,7 @@ from . import _native
 from . import common
 from . import mapper
 
-__all__ = ['run', 'quantify', 'em', 'output_results', 'bootstrap_quantify']
+__all__ = ['run', 'quantify', 'quantify_resident', 'em', 'output_results', 'bootstrap_quantify']
 
 _LOG = logging.getLogger(__name__)
 
@@ -186,6 +186,27 @@ def quantify(results, x0=None, bootstrap=False, seed=None, fixed_iters=0, return
             quant.close()
     x = _tpm(x)
     return (x, iters) if return_iters else x
+
+
+def quantify_resident(map_result, comm=None, return_iters=False, return_effective_lengths=False):
+    """quantify(map_result.summarize()) without the class table leaving the GPU
+    (seekmer/infer.py:88-130 + seekmer/mapper.py:134-141) -- one native call:
+    fragment-length histogram (all-reduced over `comm`, an skm_comm handle, when
+    given) -> effective lengths -> start vector -> EM -> TPM."""
+    length = numpy.ascontiguousarray(map_result.index.transcripts['length'], dtype='f8')
+    tpm = numpy.zeros(length.size, dtype='f8')
+    eff = numpy.zeros(length.size, dtype='f8') if return_effective_lengths else None
+    iters = ctypes.c_int64()
+    _native.check(_native.hip().skm_quant_infer(
+        map_result._handle, comm, _native.ptr(length, _native.c_f64p), length.size, REL_TOL, X_FLOOR, 0,
+        _native.ptr(tpm, _native.c_f64p), _native.ptr(eff, _native.c_f64p) if eff is not None else None,
+        ctypes.byref(iters)))
+    out = (tpm,)
+    if return_iters:
+        out += (iters.value,)
+    if return_effective_lengths:
+        out += (eff,)
+    return out if len(out) > 1 else tpm
 
 
 def bootstrap_quantify(results, x0, n_boot, seed=None):

@@ -247,7 +247,7 @@ class MapResult:
         out = (ctypes.c_double * 8)()
         _native.check(_native.hip().skm_mapper_timing(self._handle, out))
         return {'pack_ns': out[0], 'map_ns': out[1], 'class_ns': out[2],
-                'batches': int(out[3]), 'units': int(out[4])}
+                'batches': int(out[3]), 'units': int(out[4]), 'em_ns': out[5], 'em_iterations': int(out[6])}
 
 
 class ReadMapper:

@@ -181,6 +181,39 @@ def test_config1_synthetic(oracle, native_libs):
         np.testing.assert_allclose(x_gpu, x_ref, rtol=1e-9, atol=1e-300)
 
 
+def test_quantify_resident_matches_host_path(oracle, native_libs):
+    """skm_quant_infer (histogram -> effective lengths -> numpy-exact start vector -> EM ->
+    TPM on the device) against MapResult.summarize() + quantify(), which does the vector
+    arithmetic in numpy as the reference does, and against the oracle."""
+    from seekmer_amd import synth, index_builder, infer
+    ids, pool, tx_offsets = synth.transcriptome(3, 60)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    oindex = oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                                lengths=np.diff(tx_offsets))
+    n_units = 40000
+    bases, offsets = synth.reads(3, pool, tx_offsets, 0, n_units, 100, True)
+    result, _ = _run_gpu(index, bases, offsets, n_units, True)
+    tpm_dev, iters_dev, eff_dev = infer.quantify_resident(result, return_iters=True,
+                                                          return_effective_lengths=True)
+    summarized = result.summarize()
+    tpm_host, iters_host = infer.quantify(summarized, return_iters=True)
+    np.testing.assert_array_equal(eff_dev, summarized.effective_lengths)
+    assert iters_dev == iters_host
+    # same start vector bit for bit (numpy's blocked pairwise sum restated on the device), same
+    # EM kernels, same TPM arithmetic: the two paths agree to the last bit
+    np.testing.assert_array_equal(tpm_dev, tpm_host)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(oindex, bases, offsets, n_units, True, fld)
+    classes = oracle.Classes()
+    classes.update(expected)
+    class_map, class_count = classes.summarize()
+    tpm_ref, iters_ref = oracle.quantify(oracle.effective_lengths(fld, oindex.lengths), class_map, class_count)
+    assert iters_dev == iters_ref
+    mask = tpm_ref > 0
+    np.testing.assert_array_equal(tpm_dev > 0, mask)
+    assert (np.abs(tpm_dev[mask] - tpm_ref[mask]) / tpm_ref[mask]).max() < 1e-4
+
+
 def test_batches_accumulate(oracle, native_libs, chr21, chr21_oracle_index):
     """Several batches into one MapResult == one big batch (first-seen order kept)."""
     from seekmer_amd import mapper, common
