@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -1189,10 +1190,21 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         return fail(SKM_ERR_ARG, "communicator and mapper live on different GPUs");
     SKM_TRY(set_device(m->ix->device));
     const int64_t C = m->host_classes, M = m->host_arena_used;
+    // SKM_TRACE_INFER=1: host wall time between the phases below, on stderr (tuning aid)
+    static const bool trace = getenv("SKM_TRACE_INFER") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[skm_quant_infer] %-12s %8.1f us\n", what,
+                std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = now;
+    };
     skm_quant *q = new skm_quant();
     int rc = quant_alloc(q, m->ix->device, n_tx, C, M);
     if (rc != SKM_OK) { delete q; return rc; }
     if (comm) { q->comm = comm->comm; q->rank = comm->rank; q->world = comm->world; }
+    lap("alloc");
     DBuf<unsigned long long> fld;
     DBuf<double> sums;
     const int64_t n_blocks = (n_tx + 8191) / 8192;
@@ -1221,9 +1233,12 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         launch_reciprocal(q->eff_len.p, n_tx, q->x0.p, q->stream);
         launch_np_sum(q->x0.p, n_tx, 1.0, sums.p, total, q->stream);
         launch_divide(q->x0.p, n_tx, total, false, 0.0, q->stream);
+        lap("start vector");
         SKM_TRY(quant_finish_setup(q, &m->t));
+        lap("setup");
         int64_t it = 0;
         SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, &it));
+        lap("em");
         m->t_em_ns += q->t_em_ns;
         m->em_iters += (double)it;
         double *const x = (it & 1) ? q->x1.p : q->x0.p;
@@ -1234,6 +1249,7 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         HIP_TRY(hipGetLastError());
         if (tpm) HIP_TRY(hipMemcpyAsync(tpm, x, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
         HIP_TRY(hipStreamSynchronize(q->stream));
+        lap("tpm");
         if (iters) *iters = it;
         return SKM_OK;
     };
@@ -1241,6 +1257,7 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
     fld.release();
     sums.release();
     skm_quant_destroy(q);
+    lap("destroy");
     return rc;
 }
 

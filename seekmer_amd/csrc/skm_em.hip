@@ -328,47 +328,92 @@ void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream
 // that a split at n/2 rounded down to a multiple of 8 (numpy/_core/src/umath/
 // loops_utils.h.src).  The start vector x /= x.sum() (seekmer/infer.py:118-119)
 // and the TPM scaling (:127-129) go through it, so doing them on the device
-// without it would move the EM input by an ulp.  One lane per block: 8192
-// dependent adds are ~40 us, and there are only T/8192 blocks.
-// (the recursion is spelled as a chain of distinct functions, one per level, so
-// that the call graph is static: 8192 elements split at most 7 times)
-template <int LEVELS>
-__device__ __attribute__((noinline)) double np_pairwise(const double *a, int n)
+// without it would move the EM input by an ulp.
+// The tree is evaluated in three steps per block of 8192: lane 0 walks the
+// recursion and lists its leaves (at most 128 elements each), one lane per leaf
+// adds its leaf up exactly as numpy does, lane 0 walks the recursion again
+// combining the leaf sums.  (The recursion is spelled as a chain of distinct
+// functions, one per level, so that the call graph is static: 8192 elements
+// split at most 7 times.)
+constexpr int NP_MAX_LEAVES = 160;
+
+__device__ __forceinline__ double np_leaf_sum(const double *a, int n)
 {
     if (n < 8) {
         double r = 0.0;                      // numpy starts from -0.0 + a[0]; same value for our data
         for (int i = 0; i < n; ++i) r += a[i];
         return r;
     }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+template <int LEVELS>
+__device__ __attribute__((noinline)) void np_list_leaves(int lo, int n, int *leaf_lo, int *leaf_n, int *count)
+{
     if (n <= 128) {
-        double r[8];
-        for (int j = 0; j < 8; ++j) r[j] = a[j];
-        int i = 8;
-        for (; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += a[i];
-        return res;
+        if (*count < NP_MAX_LEAVES) { leaf_lo[*count] = lo; leaf_n[*count] = n; }
+        ++*count;
+        return;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
-    return np_pairwise<LEVELS - 1>(a, n2) + np_pairwise<LEVELS - 1>(a + n2, n - n2);
+    np_list_leaves<LEVELS - 1>(lo, n2, leaf_lo, leaf_n, count);
+    np_list_leaves<LEVELS - 1>(lo + n2, n - n2, leaf_lo, leaf_n, count);
 }
 template <>
-__device__ __attribute__((noinline)) double np_pairwise<0>(const double *a, int n)
+__device__ __attribute__((noinline)) void np_list_leaves<0>(int, int, int *, int *, int *count)
 {
-    double r = 0.0;                          // not reached for blocks of at most 8192 elements
-    for (int i = 0; i < n; ++i) r += a[i];
-    return r;
+    *count = NP_MAX_LEAVES + 1;              // not reached for blocks of at most 8192 elements
 }
 
-__global__ void __launch_bounds__(64)
+template <int LEVELS>
+__device__ __attribute__((noinline)) double np_combine(int n, const double *leaf_sum, int *next)
+{
+    if (n <= 128) return leaf_sum[(*next)++];
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const double left = np_combine<LEVELS - 1>(n2, leaf_sum, next);
+    const double right = np_combine<LEVELS - 1>(n - n2, leaf_sum, next);
+    return left + right;
+}
+template <>
+__device__ __attribute__((noinline)) double np_combine<0>(int, const double *, int *) { return 0.0; }
+
+__global__ void __launch_bounds__(NP_MAX_LEAVES)
 np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ block_sums)
 {
-    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t first = b * 8192;
-    if (first >= n) return;
-    block_sums[b] = np_pairwise<8>(a + first, (int)min((int64_t)8192, n - first));
+    __shared__ int leaf_lo[NP_MAX_LEAVES], leaf_n[NP_MAX_LEAVES], n_leaves;
+    __shared__ double leaf_sum[NP_MAX_LEAVES];
+    const int64_t first = blockIdx.x * (int64_t)8192;
+    const int len = (int)min((int64_t)8192, n - first);
+    if (threadIdx.x == 0) {
+        int count = 0;
+        np_list_leaves<8>(0, len, leaf_lo, leaf_n, &count);
+        n_leaves = count;
+    }
+    __syncthreads();
+    if (n_leaves > NP_MAX_LEAVES) {          // cannot happen; keep the result defined
+        if (threadIdx.x == 0) {
+            double r = 0.0;
+            for (int i = 0; i < len; ++i) r += a[first + i];
+            block_sums[blockIdx.x] = r;
+        }
+        return;
+    }
+    if ((int)threadIdx.x < n_leaves)
+        leaf_sum[threadIdx.x] = np_leaf_sum(a + first + leaf_lo[threadIdx.x], leaf_n[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int next = 0;
+        block_sums[blockIdx.x] = np_combine<8>(len, leaf_sum, &next);
+    }
 }
 
 // out[0] = the sum, out[1] = sum / divisor
@@ -406,7 +451,7 @@ void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sum
 {
     const int64_t n_blocks = (n + 8191) / 8192;
     if (n_blocks)
-        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0, stream,
+        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks), dim3(NP_MAX_LEAVES), 0, stream,
                            a, n, block_sums);
     hipLaunchKernelGGL(np_sum_final_kernel, dim3(1), dim3(1), 0, stream, block_sums, n_blocks, divisor, out);
 }

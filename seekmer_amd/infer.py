@@ -193,9 +193,9 @@ def quantify_resident(map_result, comm=None, return_iters=False, return_effectiv
     (seekmer/infer.py:88-130 + seekmer/mapper.py:134-141) -- one native call:
     fragment-length histogram (all-reduced over `comm`, an skm_comm handle, when
     given) -> effective lengths -> start vector -> EM -> TPM."""
-    length = numpy.ascontiguousarray(map_result.index.transcripts['length'], dtype='f8')
-    tpm = numpy.zeros(length.size, dtype='f8')
-    eff = numpy.zeros(length.size, dtype='f8') if return_effective_lengths else None
+    length = map_result.transcript_lengths
+    tpm = numpy.empty(length.size, dtype='f8')
+    eff = numpy.empty(length.size, dtype='f8') if return_effective_lengths else None
     iters = ctypes.c_int64()
     _native.check(_native.hip().skm_quant_infer(
         map_result._handle, comm, _native.ptr(length, _native.c_f64p), length.size, REL_TOL, X_FLOOR, 0,

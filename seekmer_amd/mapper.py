@@ -199,8 +199,17 @@ class MapResult:
         denominator = (fld[1:].astype('f8') / numpy.arange(1, MAX_FRAGMENT_LENGTH)).sum()
         return numerator / denominator
 
+    @property
+    def transcript_lengths(self):
+        """index.transcripts['length'] as a contiguous f8 array (extracted once)."""
+        cached = getattr(self, '_lengths', None)
+        if cached is None:
+            cached = numpy.ascontiguousarray(self.index.transcripts['length'], dtype='f8')
+            self._lengths = cached
+        return cached
+
     def _effective_lengths(self, fld):
-        length = numpy.ascontiguousarray(self.index.transcripts['length'], dtype='f8')
+        length = self.transcript_lengths
         out = numpy.zeros(length.shape, dtype='f8')
         _native.check(_native.hip().skm_effective_lengths(
             self.device, _native.ptr(numpy.ascontiguousarray(fld, dtype=numpy.int64), _native.c_i64p),
