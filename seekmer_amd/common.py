@@ -102,12 +102,53 @@ class KMerIndex:
 
     @classmethod
     def load(cls, path):
-        """Load an index written by :meth:`save`."""
+        """Load an index written by :meth:`save`.  The big arrays are memory-mapped
+        straight out of the (uncompressed) container instead of being copied through
+        the zip reader -- 2.2 GB at 190k transcripts, 2.0 s of a `seekmer infer` run --
+        so the pages go from the page cache to the GPU upload and nowhere else."""
+        mapped = _map_npz_members(str(path))
         with numpy.load(str(path), allow_pickle=False) as data:
             if str(data['seekmer_version']) != _INDEX_VERSION:
                 raise RuntimeError('invalid index version.')     # seekmer/_common.pyx:303-304
-            return cls(data['kmers'], data['contigs'], data['sequences'], data['targets'],
+
+            def member(name):
+                return mapped[name] if name in mapped else data[name]
+
+            return cls(member('kmers'), member('contigs'), member('sequences'), member('targets'),
                        data['transcripts'], data['exons'])
+
+
+def _map_npz_members(path, names=('kmers', 'contigs', 'sequences', 'targets')):
+    """numpy.memmap views of the named members of an .npz, for members that are stored
+    (not deflated) plain-dtype .npy files; anything else is left to numpy.load."""
+    import struct
+    import zipfile
+    out = {}
+    try:
+        with zipfile.ZipFile(path) as archive, open(path, 'rb') as raw:
+            for info in archive.infolist():
+                name = info.filename[:-4] if info.filename.endswith('.npy') else info.filename
+                if name not in names or info.compress_type != zipfile.ZIP_STORED:
+                    continue
+                raw.seek(info.header_offset)
+                header = raw.read(30)
+                if header[:4] != b'PK\x03\x04':
+                    continue
+                name_len, extra_len = struct.unpack('<HH', header[26:30])
+                raw.seek(info.header_offset + 30 + name_len + extra_len)
+                version = numpy.lib.format.read_magic(raw)
+                if version == (1, 0):
+                    shape, fortran, dtype = numpy.lib.format.read_array_header_1_0(raw)
+                elif version == (2, 0):
+                    shape, fortran, dtype = numpy.lib.format.read_array_header_2_0(raw)
+                else:
+                    continue
+                if fortran or dtype.hasobject or len(shape) != 1 or shape[0] == 0:
+                    continue
+                out[name] = numpy.memmap(path, dtype=dtype, mode='r', offset=raw.tell(), shape=shape)
+    except (OSError, ValueError, zipfile.BadZipFile):
+        return {}
+    return out
 
 
 # ------------------------------------------------------------------ file input

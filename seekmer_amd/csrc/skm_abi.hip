@@ -12,6 +12,7 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -296,14 +297,34 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     if (max_tc >= (1LL << 22))
         return fail(SKM_ERR_ARG, "a contig lists %lld targets (limit 4194303)", (long long)max_tc);
     const IndexEntry *hk = (const IndexEntry *)kmers;
+    // (2 GiB of slots at 190k transcripts: checked by all host cores)
+    const int n_workers = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(
+                              std::max(1u, std::thread::hardware_concurrency()), 16u), n_slots >> 20));
+    std::vector<int64_t> empty_part((size_t)n_workers, 0), bad_part((size_t)n_workers, -1);
+    {
+        std::vector<std::thread> workers;
+        for (int w = 0; w < n_workers; ++w)
+            workers.emplace_back([&, w]() {
+                const int64_t first = n_slots * w / n_workers, last = n_slots * (w + 1) / n_workers;
+                int64_t empty = 0;
+                for (int64_t i = first; i < last; ++i) {
+                    if (hk[i].kmer == KMER_INVALID) { ++empty; continue; }
+                    const int32_t e = hk[i].pos.entry < 0 ? ~hk[i].pos.entry : hk[i].pos.entry;
+                    if (hk[i].pos.offset >= 0
+                            && (e < 0 || e >= n_contigs || hk[i].pos.offset + K > hc[e].length)) {
+                        bad_part[(size_t)w] = i;
+                        break;
+                    }
+                }
+                empty_part[(size_t)w] = empty;
+            });
+        for (auto &t : workers) t.join();
+    }
     int64_t empty = 0;
-    for (int64_t i = 0; i < n_slots; ++i) {
-        if (hk[i].kmer == KMER_INVALID) { ++empty; continue; }
-        const int32_t e = hk[i].pos.entry < 0 ? ~hk[i].pos.entry : hk[i].pos.entry;
-        if (hk[i].pos.offset >= 0) {
-            if (e < 0 || e >= n_contigs || hk[i].pos.offset + K > hc[e].length)
-                return fail(SKM_ERR_ARG, "k-mer slot %lld points outside its contig", (long long)i);
-        }
+    for (int w = 0; w < n_workers; ++w) {
+        if (bad_part[(size_t)w] >= 0)
+            return fail(SKM_ERR_ARG, "k-mer slot %lld points outside its contig", (long long)bad_part[(size_t)w]);
+        empty += empty_part[(size_t)w];
     }
     if (empty == 0) return fail(SKM_ERR_ARG, "k-mer table has no empty slot");
 

@@ -141,6 +141,47 @@ def test_edge_windows_and_pool_fallback(oracle, native_libs, chr21, chr21_oracle
     _compare_tables(oracle, expected, fld, result)
 
 
+def test_unsorted_target_slices_take_the_walks(oracle, native_libs, chr21, chr21_oracle_index):
+    """The register paths for short lists assume every target slice ascends by signed entry
+    (true of any built index, verified at upload: skm_index_info[7]).  An index whose slices are
+    out of order must be mapped with the reference's two-pointer walks (_common.pyx:185-235,
+    _mapper.pyx:350-397), whatever they make of it."""
+    rng = np.random.default_rng(29)
+    reads = _adversarial_reads(chr21[1], rng, 4000, 100)
+    bases, offsets = oracle.pack_reads(reads)
+    targets = chr21_oracle_index.targets.copy()
+    contigs = chr21_oracle_index.contigs
+    swapped = 0
+    for c in range(0, contigs.size, 2):
+        first, n = int(contigs['target_offset'][c]), int(contigs['target_count'][c])
+        if n >= 2 and targets['entry'][first] != targets['entry'][first + n - 1]:
+            targets[[first, first + n - 1]] = targets[[first + n - 1, first]]
+            swapped += 1
+    assert swapped > 100
+    shuffled = oracle.OracleIndex(chr21_oracle_index.kmers, contigs, chr21_oracle_index.sequences,
+                                  targets, lengths=chr21_oracle_index.lengths)
+    index = make_product_index(shuffled, chr21[0])
+    assert index.device_info()['sorted_targets'] == 0
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(shuffled, bases, offsets, len(reads) // 2, True, fld)
+    result, units = _run_gpu(index, bases, offsets, len(reads) // 2, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
+def test_quantify_resident_without_classes(oracle, native_libs, chr21, chr21_oracle_index):
+    """Nothing mapped: quantify() returns zeros (seekmer/infer.py:106-107), no EM step."""
+    from seekmer_amd import infer
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    rng = np.random.default_rng(31)
+    reads = [bytes(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), 60)) for _ in range(64)]
+    bases, offsets = oracle.pack_reads(reads)
+    result, _ = _run_gpu(index, bases, offsets, 32, True)
+    assert result.sizes()[0] == 0
+    tpm, iters = infer.quantify_resident(result, return_iters=True)
+    assert iters == 0 and not tpm.any()
+
+
 def test_config1_synthetic(oracle, native_libs):
     """BASELINE.json configs[0]: 1k-transcript synthetic index, 100k 2x75 pairs."""
     from seekmer_amd import synth, index_builder, infer
