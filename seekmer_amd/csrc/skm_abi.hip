@@ -1103,7 +1103,8 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     // (a converged EM turns at most one chunk of launches into no-ops).
     auto enqueue_chunk = [&](int slot) -> int {
         for (int64_t i = 0; i < chunk; ++i, ++k) {
-            launch_em_inner(p, (int)(k & 1), q->stream);
+            // (the first step of a chunk follows the chunk-end em_decide: already judged)
+            launch_em_inner(p, (int)(k & 1), i > 0, k, q->stream);
             launch_em_rows(p, (int)(k & 1), q->stream);
             if (q->comm) {
                 launch_em_rows_to_acc(p, q->stream);
@@ -1111,8 +1112,10 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
                                           q->comm, q->stream));
             }
             launch_em_finalize(p, (int)(k & 1), q->comm != nullptr, q->stream);
-            q->launches += q->comm ? 5 : 4;
+            q->launches += q->comm ? 4 : 3;
         }
+        launch_em_decide(p, k, q->stream);
+        q->launches += 1;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(q->pinned + 8 * slot, q->ctl.p, 8 * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, q->stream));

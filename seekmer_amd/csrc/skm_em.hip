@@ -13,11 +13,13 @@
 //                   sum of x_t / inner_c over the run          (infer.py:157)
 //   em_finalize  -- one lane per transcript: x'_t = (sum of its rows) / l_t /
 //                   n, NaN -> 0, relative change against x_t; block partials
-//   em_decide    -- one block: reduces the partials, evaluates the reference's
-//                   stopping rule (infer.py:160) and latches `done`, after
-//                   which every later launch is a no-op -- the host enqueues
-//                   steps in chunks and still stops at exactly the reference's
-//                   iteration count.
+//   (judging)    -- the reference's stopping rule (infer.py:160) over the block
+//                   partials is evaluated at the head of the next em_inner
+//                   launch (every block, redundantly) and by a one-block
+//                   em_decide launch at the end of each enqueued chunk; it
+//                   latches `done`, after which every later launch is a no-op
+//                   -- the host enqueues steps in chunks and still stops at
+//                   exactly the reference's iteration count.
 // All three are gather/stream kernels bound by HBM/L2 bandwidth: no MFMA.
 #include "skm_kernels.h"
 
@@ -25,10 +27,25 @@ namespace skm {
 
 enum { CTL_DONE = 0, CTL_ITERS = 1, CTL_UNDEFINED = 3 };
 
+__device__ bool em_evaluate(const EmProblem &p, int n_parts, int64_t steps_done, bool publish);
+
+// eval_parts > 0: the finalize pass before this launch (number `steps_done`) has not been
+// judged yet -- do it here, in every block, before starting the next step
 __global__ void __launch_bounds__(256)
-em_inner_kernel(EmProblem p, int parity)
+em_inner_kernel(EmProblem p, int parity, int eval_parts, int64_t steps_done)
 {
-    if (p.ctl[CTL_DONE]) return;
+    if (eval_parts > 0) {
+        // block 0 of this very launch may be latching `done` right now: take ONE reading per
+        // block (a lane-by-lane reading could split the block in front of the barrier inside
+        // em_evaluate); either reading leads to the same verdict
+        __shared__ int s_latched;
+        if (threadIdx.x == 0) s_latched = p.ctl[CTL_DONE] != 0;
+        __syncthreads();
+        if (s_latched) return;
+        if (em_evaluate(p, eval_parts, steps_done, blockIdx.x == 0)) return;
+    } else if (p.ctl[CTL_DONE]) {
+        return;
+    }
     const double *__restrict__ x = p.x[parity];
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < p.n_classes;
          c += (int64_t)gridDim.x * blockDim.x) {
@@ -127,20 +144,22 @@ em_finalize_kernel(EmProblem p, int parity)
         double m = s_max[0];
         unsigned int f = s_flags[0];
         for (int w = 1; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
-        p.part_max[blockIdx.x] = m;             // reduced by em_decide_kernel (next launch)
+        p.part_max[blockIdx.x] = m;             // judged by em_evaluate in the next launch
         p.part_flags[blockIdx.x] = f;
     }
 }
 
-// One block: reduce the per-block partials of the finalize launch before it and
-// apply the reference's stopping rule (infer.py:160).  A launch boundary is
-// cheaper here than hundreds of tickets on one device-scope counter.
-__global__ void __launch_bounds__(256)
-em_decide_kernel(EmProblem p, int n_parts)
+// The stopping rule (infer.py:160) over the per-block partials of finalize pass number
+// `steps_done` (1-based).  Every lane of the calling block takes part and gets the verdict;
+// only the caller with `publish` set writes it to the control block.  It is evaluated at the
+// head of the NEXT step's em_inner launch by every block redundantly (744 partials from L2
+// are cheaper than a launch of their own, 4.4 us), and by a one-block launch at the end of
+// each enqueued chunk so that the host can read the state.
+__device__ bool em_evaluate(const EmProblem &p, int n_parts, int64_t steps_done, bool publish)
 {
-    if (p.ctl[CTL_DONE]) return;
     __shared__ double s_max[4];
     __shared__ unsigned int s_flags[4];
+    __shared__ int s_done;
     double m = 0.0;
     unsigned int f = 0;
     for (int b = threadIdx.x; b < n_parts; b += blockDim.x) {
@@ -158,20 +177,32 @@ em_decide_kernel(EmProblem p, int n_parts)
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 0; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
-        const unsigned long long iters = p.ctl[CTL_ITERS] + 1;
-        bool done;
+        bool done, undefined = false;
         if (p.fixed_iters > 0) {
-            done = (int64_t)iters >= p.fixed_iters;
+            done = steps_done >= p.fixed_iters;
         } else if (!(f & 1u)) {
-            p.ctl[CTL_UNDEFINED] = 1;         // numpy raises on max() of an empty selection
+            undefined = true;                 // numpy raises on max() of an empty selection
             done = true;
         } else {
             done = (f & 2u) || !(m > p.rel_tol);                 // NaN propagates through max()
-            if (p.max_iters > 0 && (int64_t)iters >= p.max_iters) done = true;
+            if (p.max_iters > 0 && steps_done >= p.max_iters) done = true;
         }
-        p.ctl[CTL_ITERS] = iters;
-        p.ctl[CTL_DONE] = done ? 1ULL : 0ULL;
+        if (publish) {
+            if (undefined) p.ctl[CTL_UNDEFINED] = 1;
+            p.ctl[CTL_ITERS] = (unsigned long long)steps_done;
+            p.ctl[CTL_DONE] = done ? 1ULL : 0ULL;
+        }
+        s_done = done ? 1 : 0;
     }
+    __syncthreads();
+    return s_done != 0;
+}
+
+__global__ void __launch_bounds__(256)
+em_decide_kernel(EmProblem p, int n_parts, int64_t steps_done)
+{
+    if (p.ctl[CTL_DONE]) return;
+    em_evaluate(p, n_parts, steps_done, true);
 }
 
 // MapResult.effective_lengths, mapper.py:134-141: p = fld / fld.sum();
@@ -293,9 +324,23 @@ static inline unsigned chip_grid(int64_t work_items, int items_per_block)
     return (unsigned)blocks;
 }
 
-void launch_em_inner(const EmProblem &p, int parity, hipStream_t stream)
+int em_final_blocks(const EmProblem &p)
 {
-    hipLaunchKernelGGL(em_inner_kernel, dim3(chip_grid(p.n_classes, 256)), dim3(256), 0, stream, p, parity);
+    int64_t blocks = (p.n_tx + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
+    return (int)blocks;
+}
+
+void launch_em_inner(const EmProblem &p, int parity, bool judge_previous, int64_t steps_done, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_inner_kernel, dim3(chip_grid(p.n_classes, 256)), dim3(256), 0, stream, p, parity,
+                       judge_previous ? em_final_blocks(p) : 0, steps_done);
+}
+
+void launch_em_decide(const EmProblem &p, int64_t steps_done, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_decide_kernel, dim3(1), dim3(256), 0, stream, p, em_final_blocks(p), steps_done);
 }
 
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream)
@@ -310,14 +355,11 @@ void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream)
 
 void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream)
 {
-    int64_t blocks = (p.n_tx + 255) / 256;
-    if (blocks < 1) blocks = 1;
-    if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
+    const int blocks = em_final_blocks(p);
     if (from_acc)
         hipLaunchKernelGGL(em_finalize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, parity);
     else
         hipLaunchKernelGGL(em_finalize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, parity);
-    hipLaunchKernelGGL(em_decide_kernel, dim3(1), dim3(256), 0, stream, p, (int)blocks);
 }
 
 // ---- numpy.sum of a contiguous f8 array, bit for bit ----------------------

@@ -130,7 +130,9 @@ struct EmProblem {
     int64_t max_iters, fixed_iters;
 };
 constexpr int EM_FINAL_BLOCKS = 1024;
-void launch_em_inner(const EmProblem &p, int parity, hipStream_t stream);
+// judge_previous: apply the stopping rule to finalize pass `steps_done` first (see em_evaluate)
+void launch_em_inner(const EmProblem &p, int parity, bool judge_previous, int64_t steps_done, hipStream_t stream);
+void launch_em_decide(const EmProblem &p, int64_t steps_done, hipStream_t stream);
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream);
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream);
 void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream);
