@@ -256,7 +256,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     if (n_slots <= 0 || (n_slots & (n_slots - 1)) || n_slots > (1LL << 31))
         return fail(SKM_ERR_ARG, "k-mer table size %lld is not a power of two <= 2^31", (long long)n_slots);
     if (n_contigs <= 0 || n_bases < ALIGN_LENGTH || n_targets < 0 || n_bases >= (1LL << 31)
-            || n_targets >= (1LL << 31) || n_contigs >= (1LL << 31))
+            || n_targets >= (1LL << 30) || n_contigs >= (1LL << 27))
         return fail(SKM_ERR_ARG, "bad index sizes");
     int n_dev = 0;
     SKM_TRY(skm_device_count(&n_dev));

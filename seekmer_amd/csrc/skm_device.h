@@ -57,6 +57,16 @@ struct DevIndex {
 
 __device__ __forceinline__ Coord invalid_coord() { return Coord{0, -1}; }  // _coordinate.pxd:13-24
 
+// Row `index` of the contig table through a 32-bit byte offset from the
+// (wave-uniform) base pointer: scalar base + vector offset addressing instead
+// of a 64-bit address computation per access (skm_index_create bounds
+// n_contigs by 2^27).
+__device__ __forceinline__ const DevContig &contig_at(const DevIndex &ix, int32_t index)
+{
+    return *reinterpret_cast<const DevContig *>(reinterpret_cast<const char *>(ix.contigs)
+                                                + ((uint32_t)index << 5));
+}
+
 // _kmer.pxd:146-171: reverse the 2-bit groups of the 64-bit word, shift the
 // 50 payload bits down, complement.
 __device__ __forceinline__ uint64_t kmer_revcomp(uint64_t k)
@@ -178,7 +188,7 @@ template <bool STATS>
 __device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, bool leading, LaneStats *st)
 {
     int32_t index = c.entry < 0 ? ~c.entry : c.entry;
-    int64_t offset = (int64_t)ix.contigs[index].offset + c.offset;
+    int64_t offset = (int64_t)contig_at(ix, index).offset + c.offset;
     if (STATS) { st->contig_reads++; st->seq_fetches++; }
     if (c.entry >= 0) offset += leading ? ALIGN_LENGTH : K;
     else offset += leading ? K : ALIGN_LENGTH;
@@ -205,8 +215,8 @@ __device__ __forceinline__ uint32_t contig8_edge(const DevIndex &ix, Coord c, bo
     if (STATS) { st->contig_reads++; st->seq_fetches++; }
     const bool forward = c.entry >= 0;
     uint32_t v;
-    if (forward == leading) v = (uint32_t)(ix.contigs[index].first_kmer >> (2 * K - 16)) & 0xffffu;
-    else v = (uint32_t)ix.contigs[index].last_kmer & 0xffffu;
+    if (forward == leading) v = (uint32_t)(contig_at(ix, index).first_kmer >> (2 * K - 16)) & 0xffffu;
+    else v = (uint32_t)contig_at(ix, index).last_kmer & 0xffffu;
     if (!forward) v = revcomp8(v);
     return v;
 }
@@ -217,7 +227,7 @@ __device__ __forceinline__ uint64_t tail_kmer(const DevIndex &ix, Coord c, LaneS
 {
     int32_t index = c.entry < 0 ? ~c.entry : c.entry;
     if (STATS) st->contig_reads++;
-    uint64_t k = c.offset == 0 ? ix.contigs[index].first_kmer : ix.contigs[index].last_kmer;
+    uint64_t k = c.offset == 0 ? contig_at(ix, index).first_kmer : contig_at(ix, index).last_kmer;
     if (c.entry < 0) k = kmer_revcomp(k);
     return k;
 }

@@ -122,6 +122,15 @@ pack_contigs_kernel(const ContigEntry *__restrict__ in, int64_t n, DevContig *__
 // the index (L1-cacheable).  Word 0 of the mask lives with the context, words
 // 1.. (slices longer than 64 targets) in a per-context HBM extension with a
 // staging copy of the same size behind it.
+// targets[i] through a 32-bit byte offset from the (wave-uniform) base: one
+// global_load with scalar base + vector offset instead of a 64-bit address
+// computation per element (skm_index_create bounds n_targets by 2^30)
+__device__ __forceinline__ int32_t target_at(const DevIndex &ix, int32_t i)
+{
+    return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ix.targets)
+                                              + ((uint32_t)i << 2));
+}
+
 struct TSet {
     int32_t start;            // first element of the slice in ix.targets
     int32_t length;           // slice length = list positions 0 .. length-1
@@ -135,7 +144,7 @@ struct TSet {
     __device__ __forceinline__ void set_word(int w, uint64_t v) { if (w == 0) word0 = v; else ext[w - 1] = v; }
     __device__ __forceinline__ int32_t entry(const DevIndex &ix, int i) const
     {
-        return forward ? ix.targets[start + i] : ~ix.targets[start + length - 1 - i];
+        return forward ? target_at(ix, start + i) : ~target_at(ix, start + length - 1 - i);
     }
 };
 
@@ -151,8 +160,8 @@ __device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, TSet &se
 {
     const bool forward = c.entry >= 0;
     const int32_t index = forward ? c.entry : ~c.entry;
-    set.start = (int32_t)ix.contigs[index].target_offset;
-    int32_t length = (int32_t)ix.contigs[index].target_length;
+    set.start = (int32_t)contig_at(ix, index).target_offset;
+    int32_t length = (int32_t)contig_at(ix, index).target_length;
     if (length > ix.max_target_count) length = ix.max_target_count;
     set.length = length;
     set.forward = forward;
@@ -194,7 +203,7 @@ __device__ __forceinline__ void load_list(const DevIndex &ix, int32_t start, int
 #pragma unroll
     for (int i = 0; i < LIST_REGS; ++i) {
         const int p = min(i, last);
-        const int32_t raw = ix.targets[forward ? start + p : start + last - p];
+        const int32_t raw = target_at(ix, forward ? start + p : start + last - p);
         e[i] = (i <= last && ((keep >> i) & 1u)) ? (forward ? raw : ~raw) : NO_ENTRY;
     }
 }
@@ -230,8 +239,8 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
     if (span.n == 0) return true;
     const bool forward = span.anchor.entry >= 0;
     const int32_t contig = forward ? span.anchor.entry : ~span.anchor.entry;
-    const int32_t start = (int32_t)ix.contigs[contig].target_offset;
-    const int32_t length = (int32_t)ix.contigs[contig].target_length;
+    const int32_t start = (int32_t)contig_at(ix, contig).target_offset;
+    const int32_t length = (int32_t)contig_at(ix, contig).target_length;
     if (STATS) st->contig_reads++;
     if (LIST_FAST(STATS) && ix.sorted_targets && set.length <= LIST_REGS && length <= LIST_REGS) {
         if (length == 0) return false;
@@ -260,7 +269,7 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
             const int32_t target_entry = set.entry(ix, 64 * w + bit);
             int32_t index_entry = 0;
             while (track != bound) {                 // skip index entries below the list entry
-                index_entry = ix.targets[track];
+                index_entry = target_at(ix, track);
                 if (!forward) index_entry = ~index_entry;
                 if (index_entry >= target_entry) break;
                 track += step;
@@ -359,13 +368,13 @@ __device__ __forceinline__ int left_move(const DevIndex &ix, Coord a)
 {
     const bool forward = a.entry >= 0;
     const int32_t contig = forward ? a.entry : ~a.entry;
-    return forward ? a.offset : (int)ix.contigs[contig].length - a.offset - K;
+    return forward ? a.offset : (int)contig_at(ix, contig).length - a.offset - K;
 }
 __device__ __forceinline__ int right_move(const DevIndex &ix, Coord a)
 {
     const bool forward = a.entry >= 0;
     const int32_t contig = forward ? a.entry : ~a.entry;
-    return forward ? (int)ix.contigs[contig].length - a.offset - K : a.offset;
+    return forward ? (int)contig_at(ix, contig).length - a.offset - K : a.offset;
 }
 
 // _intersect, _mapper.pyx:350-397: mate 1 ascending against mate 2 walked from
@@ -539,11 +548,18 @@ map_units_kernel(DevIndex ix, MapBatch b)
     uint32_t idle_spins = 0;
     for (;;) {
         // ------------------------------------------------ pick the most backed-up action
+        // (lane a reads queue a: one LDS round trip for all six, then scalar compares)
+        uint32_t my_head = 0, my_tail = 0;
+        if (lane < N_ACTIONS) {
+            my_head = *(volatile uint32_t *)&q_head[lane];
+            my_tail = *(volatile uint32_t *)&q_tail[lane];
+        }
         int action = -1;
         uint32_t avail = 0, head = 0;
+#pragma unroll
         for (int a = 0; a < N_ACTIONS; ++a) {
-            const uint32_t h = *(volatile uint32_t *)&q_head[a];
-            const uint32_t t = *(volatile uint32_t *)&q_tail[a];
+            const uint32_t h = __builtin_amdgcn_readlane(my_head, a);
+            const uint32_t t = __builtin_amdgcn_readlane(my_tail, a);
             if (t - h > avail && (int)(t - h) >= 0) { avail = t - h; action = a; head = h; }
         }
         if (*(volatile uint32_t *)&stalled) break;        // a bounded spin gave up: drain, host reports it
