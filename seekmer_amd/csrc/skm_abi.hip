@@ -534,6 +534,12 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(m->workspace.ensure((size_t)(blocks * CONTEXTS * 4 * ext_words * 2 + 16)));
     SKM_TRY(m->mate1.ensure((size_t)(blocks * CONTEXTS) * 48));
     m->grid_blocks = (int)blocks;
+    {   // the kernel addresses a block's records with 32-bit byte offsets
+        const int64_t per_block = (n_units + blocks - 1) / blocks;
+        if (per_block * (paired ? 2 : 1) * (int64_t)record_words * 4 >= (1LL << 32))
+            return fail(SKM_ERR_ARG, "batch of %lld units with %d-base reads is too large for one launch",
+                        (long long)n_units, max_len);
+    }
     // entry arena: ~8 ids per unit plus one 2048-id slice of slack per wave
     SKM_TRY(m->unit_entries.ensure((size_t)n_units * 8 + (size_t)blocks * (MAP_THREADS / 64) * 2048 + 4096));
 

@@ -238,38 +238,64 @@ __device__ __forceinline__ uint64_t tail_kmer(const DevIndex &ix, Coord c, LaneS
 // (_mapper.pyx:500-501).
 // One record per read, 64-byte aligned: W code words (u64), W mask words (u32,
 // 32 bases per word, first base in the top bit), then the read length (u32).
+// A view addresses its record as (wave-uniform base, 32-bit byte offset): the
+// loads then take the scalar-base + vector-offset form and no lane computes a
+// 64-bit address.
 struct ReadView {
-    const uint64_t *codes;
-    const uint32_t *acgt;
+    const char *base;          // wave-uniform: the first record of the block's range
+    uint32_t off;              // byte offset of this read's record from `base`
+    int words;                 // W
     int len;
+    __device__ __forceinline__ uint64_t code_word(int w) const
+    {
+        return *reinterpret_cast<const uint64_t *>(base + (off + ((uint32_t)w << 3)));
+    }
+    __device__ __forceinline__ uint32_t mask_word(int w) const
+    {
+        return *reinterpret_cast<const uint32_t *>(base + (off + ((uint32_t)(2 * words + w) << 2)));
+    }
+    __device__ __forceinline__ uint32_t stored_length() const
+    {
+        return *reinterpret_cast<const uint32_t *>(base + (off + ((uint32_t)(3 * words) << 2)));
+    }
 };
-__device__ __forceinline__ ReadView read_view(const uint32_t *records, int record_words, int words_per_read,
-                                              int64_t r)
+// record `local` (counted from the block's first record) of a batch with record_words u32 per record
+__device__ __forceinline__ ReadView read_view(const char *block_records, int record_words, int words_per_read,
+                                              uint32_t local)
 {
-    const uint32_t *rec = records + r * (int64_t)record_words;
-    return ReadView{reinterpret_cast<const uint64_t *>(rec), rec + 2 * words_per_read,
-                    (int)rec[3 * words_per_read]};
+    ReadView r{block_records, local * ((uint32_t)record_words << 2), words_per_read, 0};
+    r.len = (int)r.stored_length();
+    return r;
 }
 
+// 32 consecutive codes of the read starting at base p (the record carries one pad word)
+__device__ __forceinline__ uint64_t read_window(const ReadView &r, int p)
+{
+    const int w = p >> 5;
+    const int s = (p & 31) << 1;
+    const uint64_t hi = r.code_word(w);
+    if (s == 0) return hi;
+    return (hi << s) | (r.code_word(w + 1) >> (64 - s));
+}
 __device__ __forceinline__ uint64_t read_kmer(const ReadView &r, int p)      // _kmer.pxd:46-68
 {
-    return packed_window(r.codes, p) >> (64 - 2 * K);
+    return read_window(r, p) >> (64 - 2 * K);
 }
 // the 16 codes of aligned half word h (bases 16h .. 16h+15), first base on top
 __device__ __forceinline__ uint32_t read_half(const ReadView &r, int h)
 {
-    return reinterpret_cast<const uint32_t *>(r.codes)[h ^ 1];
+    return *reinterpret_cast<const uint32_t *>(r.base + (r.off + ((uint32_t)(h ^ 1) << 2)));
 }
 __device__ __forceinline__ uint32_t read_code(const ReadView &r, int p)
 {
-    return (uint32_t)(r.codes[p >> 5] >> (62 - 2 * (p & 31))) & 3u;
+    return (uint32_t)(r.code_word(p >> 5) >> (62 - 2 * (p & 31))) & 3u;
 }
 // 16 bases of codes (32 bits) and 16 "is ACGT" bits starting at base p
 __device__ __forceinline__ void read_window16(const ReadView &r, int p, uint32_t &codes, uint32_t &acgt)
 {
-    codes = (uint32_t)(packed_window(r.codes, p) >> 32);
+    codes = (uint32_t)(read_window(r, p) >> 32);
     const int w = p >> 5, s = p & 31;
-    uint64_t m = ((uint64_t)r.acgt[w] << 32) | r.acgt[w + 1];
+    uint64_t m = ((uint64_t)r.mask_word(w) << 32) | r.mask_word(w + 1);
     acgt = (uint32_t)((m << s) >> 48);
 }
 

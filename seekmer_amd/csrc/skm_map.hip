@@ -524,6 +524,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
     uint64_t *const ws_block = reinterpret_cast<uint64_t *>(b.workspace)
                                + (size_t)blockIdx.x * NCTX * 4 * (size_t)ext_words;
     Mate1 *const mate1_block = reinterpret_cast<Mate1 *>(b.mate1) + (size_t)blockIdx.x * NCTX;
+    // the block's records, addressed with 32-bit byte offsets (the host checks the range fits)
+    const uint32_t record_bytes = (uint32_t)b.record_words << 2;
+    const char *const block_records = reinterpret_cast<const char *>(b.records)
+                                      + (size_t)(b.paired ? 2 * block_first : block_first) * record_bytes;
     int64_t chunk_pos = 0, chunk_end = 0;      // wave-uniform slice of the entry arena
     LaneStats ls = {0, 0, 0, 0, 0, 0, 0};
     uint64_t read_bases = 0, n_reads = 0, tuple_ids = 0;
@@ -612,12 +616,13 @@ map_units_kernel(DevIndex ix, MapBatch b)
             uint64_t *const ext2 = ext1 + 2 * (size_t)ext_words;
             TSet set{c_tstart[c], c_tlen[c] >> 1, (c_tlen[c] & 1) != 0,
                      ((uint64_t)c_mask_hi[c] << 32) | c_mask_lo[c], mate ? ext2 : ext1, ext_words};
-            ReadView rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u + mate : u);
-            rv.len = c_len[c];          // (kept with the context: saves touching the record)
+            const uint32_t first_read = b.paired ? 2u * (uint32_t)c_unit[c] : (uint32_t)c_unit[c];
+            ReadView rv{block_records, (first_read + (uint32_t)mate) * record_bytes, b.words_per_read,
+                        c_len[c]};      // (the length is kept with the context: saves touching the record)
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
             if (valid && action == A_START) {
-                rv = read_view(b.records, b.record_words, b.words_per_read, b.paired ? 2 * u : u);
+                rv = read_view(block_records, b.record_words, b.words_per_read, first_read);
                 mate = 0;
                 attempt = 0;
                 set.start = 0; set.length = 0; set.word0 = 0;   // (a context starts with whatever LDS held)
@@ -900,7 +905,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     set.word0 = 0;
                     mate = 1;
                     attempt = 0;
-                    rv = read_view(b.records, b.record_words, b.words_per_read, 2 * u + 1);
+                    rv = read_view(block_records, b.record_words, b.words_per_read, first_read + 1u);
                     span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
                     if (STATS) { read_bases += rv.len; n_reads++; }
                     if (rv.len >= K) {
