@@ -477,6 +477,43 @@ def test_other_read_lengths(oracle, native_libs, read_len, paired):
     _compare_tables(oracle, expected, fld, result)
 
 
+def test_long_and_ragged_reads(oracle, native_libs, chr21, chr21_oracle_index):
+    """Reads of 600-1500 bases cut from transcripts (several 64-byte records per read, long
+    first-k-mer rolls and many contig jumps), mixed with very short ones in one batch, single-
+    and pair-ended; then an empty batch and a batch of empty reads."""
+    from seekmer_amd import common
+    rng = np.random.default_rng(41)
+    long_tx = [s for s in chr21[1] if len(s) > 1600]
+    assert len(long_tx) > 20
+    reads = []
+    for i in range(600):
+        s = long_tx[rng.integers(len(long_tx))]
+        n = int(rng.integers(600, 1500))
+        p = int(rng.integers(0, len(s) - n))
+        r = bytearray(s[p:p + n].upper())
+        for _ in range(int(rng.integers(0, 8))):                # a few substitutions
+            r[int(rng.integers(len(r)))] = b'ACGT'[int(rng.integers(4))]
+        reads.append(bytes(r) if i % 5 else bytes(r[:int(rng.integers(0, 40))]))
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(reads)
+    for paired in (False, True):
+        n_units = len(reads) // 2 if paired else len(reads)
+        fld = np.zeros(2000, dtype=np.int64)
+        expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld)
+        result, units = _run_gpu(index, bases, offsets, n_units, paired)
+        _compare_units(expected, units)
+        _compare_tables(oracle, expected, fld, result)
+    # nothing in, nothing counted
+    result, _ = _run_gpu(index, np.zeros(1, np.uint8), np.zeros(1, np.int64), 0, True)
+    assert result.sizes() == (0, 0, 0, 0)
+    empty_offsets = np.zeros(9, dtype=np.int64)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, np.zeros(1, np.uint8), empty_offsets, 4, True, fld)
+    result, units = _run_gpu(index, np.zeros(1, np.uint8), empty_offsets, 4, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_module_surface(oracle, native_libs, chr21, chr21_oracle_index, pairs21, tmp_path):
     """The reference's module API on the device-backed MapResult: map_reads with
     worker threads and the Python feeders, Counter view, update(), clear(),
