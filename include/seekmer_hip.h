@@ -137,9 +137,10 @@ int skm_mapper_timing(skm_mapper *mapper, double stats[8]);
  * algorithmic bytes): enable, map, then read.  out[0]=reads
  * [1]=read bases [2]=lookups [3]=slots probed [4]=ContigEntry reads [5]=target
  * entries copied [6]=target entries merged [7]=8-base fetches [8]=merges
- * [9]=tuple ids; out[16..28] = scheduler census of the map kernel: rounds, then
- * (chunk executions, lanes) of start, lookup, merge, left, right, emit;
- * out[32..39] = wave-cycle sums: schedule, end-of-round barrier, then per action. */
+ * [9]=tuple ids; out[16..30] = scheduler census of the map kernel: rounds, then
+ * (chunk executions, lanes) of start, lookup, merge, left, right, emit, scan;
+ * out[32..46] = wave-cycle sums: schedule, (unused), then per action, then six
+ * phases of the emission. */
 int skm_mapper_set_stats(skm_mapper *mapper, int enable);
 int skm_mapper_access_stats(skm_mapper *mapper, int64_t out[48]);
 

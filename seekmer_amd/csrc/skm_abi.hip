@@ -129,7 +129,7 @@ struct skm_mapper {
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
     double t_em_ns = 0, em_iters = 0;          // skm_quant_infer calls on this mapper
     unsigned long long stats_total[48] = {0};
-    int vote[8] = {1, 1, 1, 1, 1, 1, 0, 0};   // quorum per action (start, lookup, merge, left, right, emit)
+    int vote[8] = {1, 1, 1, 1, 1, 1, 1, 0};   // quorum per action (start, lookup, merge, left, right, emit, scan)
 };
 
 struct skm_quant {
@@ -650,9 +650,9 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void **)&m->pinned, 64 * sizeof(unsigned long long)));
     m->want_stats = getenv("SKM_MAP_STATS") != nullptr;
-    if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "start,lookup,merge,left,right,emit"
-        sscanf(v, "%d,%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4],
-               &m->vote[5]);
+    if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "start,lookup,merge,left,right,emit,scan"
+        sscanf(v, "%d,%d,%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4],
+               &m->vote[5], &m->vote[6]);
     int rc = table_reset(m, 1 << 16);
     if (rc != SKM_OK) { delete m; return rc; }
     HIP_TRY(hipStreamSynchronize(m->stream));

@@ -25,7 +25,7 @@ struct MapBatch {
     unsigned long long *ids_cursor;
     unsigned long long *fld;      // [2000] batch-local histogram
     unsigned long long *stats;    // [16] access counters (STATS build only)
-    int32_t vote[8];              // quorum per action: start, lookup, merge, left, right, emit
+    int32_t vote[8];              // quorum per action: start, lookup, merge, left, right, emit, scan
 };
 
 // map kernel geometry: lanes per persistent block and the occupancy the register

@@ -461,6 +461,11 @@ __device__ __forceinline__ uint64_t tuple_key_step(uint64_t h, uint32_t id)
 //   * a short queue is left to fill up while other waves are still producing.
 // States that wait for a lookup result:
 //   Y_FIRST  first-hit scan (_find_first_kmer)            Y_RA  right re-anchor (:283-284)
+//   Y_SCAN   the same scan once its first k-mer has missed: the read is being rolled past a
+//            sequencing error (13 further misses on average, 76 for a read that maps nowhere).
+//            These contexts have a queue of their own whose action does up to SCAN_ROUNDS
+//            lookups in a row, so the fixed cost of a scheduling round is paid once per
+//            SCAN_ROUNDS misses and the wave stays converged (every lane is rolling)
 //   Y_LJ/Y_LS left junction / skip-a-k lookup (:247-263)  Y_RJ  right junction (:309-315)
 // Other waiting states: M_* (_filter_on_contig), N_LEFT (:229-246,
 // :270-275), N_RIGHT (:285-308, :335-343), ST_NEW, ST_UNIT_DONE (map_read_pair :129-144 +
@@ -471,8 +476,10 @@ enum : int { ST_IDLE = 0, ST_NEW,
              M_LJ, M_LS, M_RJ,                         // want a list merge
              N_LEFT, N_RIGHT,                          // want an 8-base alignment step
              N_RIGHT_ENTER, N_AFTER, N_MATE_DONE,      // cheap transitions
-             ST_UNIT_DONE };                           // want emission
-enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, N_ACTIONS };
+             ST_UNIT_DONE,                             // want emission
+             Y_SCAN };                                 // want a run of lookups
+enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_ACTIONS };
+constexpr int SCAN_ROUNDS = 4;
 
 constexpr int NCTX = 512;             // unit contexts per block (LDS)
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
@@ -486,6 +493,7 @@ constexpr int FLD_WINDOW = 512;       // fragment lengths below this are counted
 __device__ __forceinline__ int action_of(int state)
 {
     if (state >= Y_FIRST && state <= Y_RJ) return A_LOOKUP;
+    if (state == Y_SCAN) return A_SCAN;
     if (state == ST_NEW) return A_START;
     if (state >= M_LJ && state <= M_RJ) return A_MERGE;
     if (state == N_LEFT) return A_LEFT;
@@ -534,7 +542,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
     uint32_t census[1 + 2 * N_ACTIONS];
     for (int i = 0; i < 1 + 2 * N_ACTIONS; ++i) census[i] = 0;
     // cycle stamps (STATS build): [0]=idle / choosing [1]=unused [2..]=per action
-    unsigned long long cyc[2 + N_ACTIONS + 6];      // [8..13]: phases of the emission
+    unsigned long long cyc[2 + N_ACTIONS + 6];      // the last six: phases of the emission
     for (int i = 0; i < 2 + N_ACTIONS + 6; ++i) cyc[i] = 0;
     unsigned long long t_mark = STATS ? clock64() : 0;
 
@@ -651,6 +659,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;   // _kmer.append
                         ++scan_i;
                         if ((scan_i & 15) == 0 && scan_i < rv.len) look = read_half(rv, scan_i >> 4);
+                        state = Y_SCAN;                       // the rest of the roll: A_SCAN
                     } else {
                         state = N_MATE_DONE;                  // no hit: returned as is, no retry
                     }
@@ -664,6 +673,25 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 } else {                                      // Y_LS :260-263, Y_RJ :312-315
                     span.n = 0;
                     state = N_AFTER;
+                }
+            } else if (valid && action == A_SCAN) {
+                // ------------- _find_first_kmer's roll, :207-216, SCAN_ROUNDS k-mers per round
+                for (int round = 0; round < SCAN_ROUNDS && state == Y_SCAN; ++round) {
+                    const Coord pos = map_kmer<STATS>(ix, kmer, &ls);
+                    span.anchor = pos;
+                    if (pos.offset >= 0) {
+                        span.begin = scan_i - K;
+                        span.end = span.begin;
+                        map_contig<STATS>(ix, pos, set, span, &ls);
+                        state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+                        anchored = true;
+                    } else if (scan_i < rv.len) {
+                        kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
+                        ++scan_i;
+                        if ((scan_i & 15) == 0 && scan_i < rv.len) look = read_half(rv, scan_i >> 4);
+                    } else {
+                        state = N_MATE_DONE;
+                    }
                 }
             } else if (valid && action == A_MERGE) {
                 // ---------------------------------- the one _filter_on_contig site
@@ -750,7 +778,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 // ---------------------------------------------- A_EMIT: finished units
                 unsigned long long t_e = STATS ? clock64() : 0;
                 auto phase = [&](int k) {
-                    if (STATS) { const unsigned long long t = clock64(); cyc[8 + k] += t - t_e; t_e = t; }
+                    if (STATS) { const unsigned long long t = clock64(); cyc[2 + N_ACTIONS + k] += t - t_e; t_e = t; }
                 };
                 int n_out = 0;
                 if (valid) {

@@ -245,9 +245,9 @@ class MapResult:
         stats = {n: int(out[i]) for i, n in enumerate(names)}
         census = ('rounds', 'start_exec', 'start_lanes', 'lookup_exec', 'lookup_lanes', 'merge_exec',
                   'merge_lanes', 'left_exec', 'left_lanes', 'right_exec', 'right_lanes', 'emit_exec',
-                  'emit_lanes')
+                  'emit_lanes', 'scan_exec', 'scan_lanes')
         stats['census'] = {n: int(out[16 + i]) for i, n in enumerate(census)}
-        cycles = ('schedule', 'barrier', 'start', 'lookup', 'merge', 'left', 'right', 'emit',
+        cycles = ('schedule', 'barrier', 'start', 'lookup', 'merge', 'left', 'right', 'emit', 'scan',
                   'emit_mate1', 'emit_intersect', 'emit_fld', 'emit_scan', 'emit_entries', 'emit_store')
         stats['wave_cycles'] = {n: int(out[32 + i]) for i, n in enumerate(cycles)}
         return stats
