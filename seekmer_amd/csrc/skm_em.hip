@@ -34,6 +34,16 @@ __device__ bool em_evaluate(const EmProblem &p, int n_parts, int64_t steps_done,
 __global__ void __launch_bounds__(256)
 em_inner_kernel(EmProblem p, int parity, int eval_parts, int64_t steps_done)
 {
+    // the first class's row is fetched before the verdict on the previous step is known: its
+    // latency then runs under the judging instead of after it
+    const int64_t c_first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t begin_first = 0, end_first = 0;
+    double count_first = 1.0;
+    if (c_first < p.n_classes) {
+        begin_first = p.cls_offset[c_first];
+        end_first = p.cls_offset[c_first + 1];
+        count_first = p.cls_count[c_first];
+    }
     if (eval_parts > 0) {
         // block 0 of this very launch may be latching `done` right now: take ONE reading per
         // block (a lane-by-lane reading could split the block in front of the barrier inside
@@ -49,8 +59,9 @@ em_inner_kernel(EmProblem p, int parity, int eval_parts, int64_t steps_done)
     const double *__restrict__ x = p.x[parity];
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < p.n_classes;
          c += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t begin = p.cls_offset[c], end = p.cls_offset[c + 1];
-        const double count = p.cls_count[c];
+        const int64_t begin = c == c_first ? begin_first : p.cls_offset[c];
+        const int64_t end = c == c_first ? end_first : p.cls_offset[c + 1];
+        const double count = c == c_first ? count_first : p.cls_count[c];
         double s = 0.0;
         int64_t j = begin;
         for (; j + 4 <= end; j += 4) {          // four independent gathers in flight, summed in order
@@ -428,13 +439,15 @@ __device__ __attribute__((noinline)) double np_combine(int n, const double *leaf
 template <>
 __device__ __attribute__((noinline)) double np_combine<0>(int, const double *, int *) { return 0.0; }
 
-__global__ void __launch_bounds__(NP_MAX_LEAVES)
+__global__ void __launch_bounds__(256)
 np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ block_sums)
 {
+    __shared__ double staged[8192];          // the block, fetched coalesced; leaves then read LDS
     __shared__ int leaf_lo[NP_MAX_LEAVES], leaf_n[NP_MAX_LEAVES], n_leaves;
     __shared__ double leaf_sum[NP_MAX_LEAVES];
     const int64_t first = blockIdx.x * (int64_t)8192;
     const int len = (int)min((int64_t)8192, n - first);
+    for (int i = threadIdx.x; i < len; i += blockDim.x) staged[i] = a[first + i];
     if (threadIdx.x == 0) {
         int count = 0;
         np_list_leaves<8>(0, len, leaf_lo, leaf_n, &count);
@@ -444,13 +457,13 @@ np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict
     if (n_leaves > NP_MAX_LEAVES) {          // cannot happen; keep the result defined
         if (threadIdx.x == 0) {
             double r = 0.0;
-            for (int i = 0; i < len; ++i) r += a[first + i];
+            for (int i = 0; i < len; ++i) r += staged[i];
             block_sums[blockIdx.x] = r;
         }
         return;
     }
     if ((int)threadIdx.x < n_leaves)
-        leaf_sum[threadIdx.x] = np_leaf_sum(a + first + leaf_lo[threadIdx.x], leaf_n[threadIdx.x]);
+        leaf_sum[threadIdx.x] = np_leaf_sum(staged + leaf_lo[threadIdx.x], leaf_n[threadIdx.x]);
     __syncthreads();
     if (threadIdx.x == 0) {
         int next = 0;
@@ -493,7 +506,7 @@ void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sum
 {
     const int64_t n_blocks = (n + 8191) / 8192;
     if (n_blocks)
-        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks), dim3(NP_MAX_LEAVES), 0, stream,
+        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream,
                            a, n, block_sums);
     hipLaunchKernelGGL(np_sum_final_kernel, dim3(1), dim3(1), 0, stream, block_sums, n_blocks, divisor, out);
 }
