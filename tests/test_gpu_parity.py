@@ -457,6 +457,51 @@ def test_full_size_properties(oracle, native_libs):
     assert single.fragment_length_counts.sum() == 2 * n_units  # every read counted
 
 
+def test_baseline_config2_properties(oracle, native_libs):
+    """BASELINE.json configs[1] at its full size -- the ~190k-transcript stand-in index
+    (2 GiB k-mer table) and 10 M 2x100 pairs, where the oracle would need a minute per run --
+    through properties that do not need it: totals, first-seen order, the same counter from two
+    uneven batches and from a second run (the scheduler is asynchronous, the integers must not
+    care), and the device quantification against the numpy one bit for bit."""
+    from seekmer_amd import synth, index_builder, mapper, common, infer
+    ids, pool, tx_offsets = synth.transcriptome(1, 20000)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    assert index.kmers.size == 1 << 27 and len(ids) > 150000
+    n_units = 10_000_000
+    bases, offsets = synth.reads(1, pool, tx_offsets, 0, n_units, 100, True)
+    whole = mapper.MapResult(index)
+    mapper.ReadMapper(index, whole).map_batch(common.ReadBatch(n_units, bases, offsets, True))
+    c, rows, unaligned, total = whole.sizes()
+    offs, targets, counts, first_seen, fld = whole.export()
+    assert total == n_units and counts.sum() + unaligned == n_units
+    assert fld[0] == 0 and 0 < fld.sum() <= counts.sum()
+    assert (np.diff(first_seen) > 0).all() and first_seen[0] >= 0 and first_seen[-1] < n_units
+    assert unaligned < 0.03 * n_units and (targets >= 0).all() and targets.max() < len(ids)
+    assert (np.diff(offs) > 0).all() and offs[-1] == rows
+
+    split = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, split)
+    cut = 3_333_333
+    rm.map_batch(common.ReadBatch(cut, bases[:offsets[2 * cut] + 1], offsets[:2 * cut + 1], True))
+    rest = offsets[2 * cut:] - offsets[2 * cut]
+    rm.map_batch(common.ReadBatch(n_units - cut, bases[offsets[2 * cut]:], np.ascontiguousarray(rest), True))
+    offs2, targets2, counts2, first2, fld2 = split.export()
+    np.testing.assert_array_equal(offs2, offs)          # same classes, same (first-seen) order
+    np.testing.assert_array_equal(targets2, targets)
+    np.testing.assert_array_equal(counts2, counts)
+    np.testing.assert_array_equal(first2, first_seen)
+    np.testing.assert_array_equal(fld2, fld)
+
+    tpm_dev, iters_dev = infer.quantify_resident(whole, return_iters=True)
+    tpm_again, iters_again = infer.quantify_resident(split, return_iters=True)
+    assert iters_dev == iters_again
+    np.testing.assert_array_equal(tpm_dev, tpm_again)   # no floating-point atomics anywhere
+    tpm_host, iters_host = infer.quantify(whole.summarize(), return_iters=True)
+    assert iters_host == iters_dev
+    np.testing.assert_array_equal(tpm_host, tpm_dev)
+    assert abs(tpm_dev.sum() - 1e6) < 1e-3
+
+
 @pytest.mark.parametrize('read_len,paired', [(150, False), (251, True), (33, True)])
 def test_other_read_lengths(oracle, native_libs, read_len, paired):
     """BASELINE.json configs[3] shape (150 bp single-ended) and reads that need
