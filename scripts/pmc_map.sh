@@ -19,5 +19,10 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
       python3 $ROOT/scripts/profile_map.py --reps 2 --cache /tmp/skm_idx.npz > $OUT/pass$i.log 2>&1
 done
 python3 $ROOT/scripts/pmc_summary.py $OUT map_units_kernel > $ROOT/gpurun_out/pmc_$TAG.json
+# further kernels of the same runs: bash scripts/pmc_map.sh <tag> class_insert_kernel class_verify_kernel ...
+shift || true
+for EXTRA in "$@"; do
+  python3 $ROOT/scripts/pmc_summary.py $OUT $EXTRA > $ROOT/gpurun_out/pmc_${TAG}_$EXTRA.json
+done
 # raw per-dispatch CSVs are large; keep the summary and the logs
 find $OUT -name "*.csv" -size +2M -delete

@@ -70,35 +70,49 @@ __global__ void __launch_bounds__(256)
 class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot,
                     unsigned long long *unit_claim, bool retry_deferred)
 {
+    // Unaligned units are tallied per block (LDS) and reach the device counter with one atomic
+    // per block: atomics on one address serialise at ~10 ns apiece.
+    __shared__ unsigned int s_unaligned;
+    if (threadIdx.x == 0) s_unaligned = 0;
+    __syncthreads();
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
-        unit_claim[u] = 0;
-        if (retry_deferred && unit_slot[u] != -2) continue;
-        const unsigned long long key = b.unit_key[u];
-        if (key == 0) {                       // empty tuple = unaligned, mapper.py:87
-            // one atomic per wave: same-address atomics serialise at one L2 channel
-            const unsigned long long peers = __ballot(1);
-            if ((int)(threadIdx.x & 63) == __builtin_ctzll(peers))
-                atomicAdd(t.n_unaligned, (unsigned long long)__popcll(peers));
-            unit_slot[u] = -1;
-            continue;
+        // every unit leaves with ONE store to unit_slot (new units) and ONE to unit_claim, issued
+        // at the end: on gfx9 a store issued before the loads would have to drain in front of them
+        unsigned long long claim = 0;
+        int64_t where = -1;
+        bool touched = true;
+        if (retry_deferred && unit_slot[u] != -2) {
+            touched = false;                  // counted in an earlier pass: only its claim is cleared
+        } else {
+            const unsigned long long key = b.unit_key[u];
+            if (key == 0) {                   // empty tuple = unaligned, mapper.py:87
+                const unsigned long long peers = __ballot(1);
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(peers))
+                    atomicAdd(&s_unaligned, (unsigned int)__popcll(peers));
+            } else {
+                bool claimed;
+                unsigned long long seen = ~0ULL;
+                const uint64_t slot = probe_claim(t, key, claimed, CLASS_PROBE_LIMIT, &seen);
+                if (slot == ~0ULL) {          // deferred: counted after the table has grown
+                    atomicAdd(t.n_deferred, 1ULL);
+                    where = -2;
+                } else {
+                    // the creator of a class stores its tuple later (class_commit_kernel): one
+                    // class (bits 40+) and n arena ids (bits 0-39), placed by a device-wide scan
+                    if (claimed) claim = (1ULL << 40) | (unsigned long long)b.unit_count[u];
+                    atomicAdd(&t.slots[slot].count, 1ULL);
+                    if (claimed || seen > (unsigned long long)(unit_base + u))
+                        atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
+                    where = (int64_t)slot;
+                }
+            }
         }
-        bool claimed;
-        unsigned long long seen = ~0ULL;
-        const uint64_t slot = probe_claim(t, key, claimed, CLASS_PROBE_LIMIT, &seen);
-        if (slot == ~0ULL) {                  // deferred: counted after the table has grown
-            atomicAdd(t.n_deferred, 1ULL);
-            unit_slot[u] = -2;
-            continue;
-        }
-        atomicAdd(&t.slots[slot].count, 1ULL);
-        if (claimed || seen > (unsigned long long)(unit_base + u))
-            atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
-        unit_slot[u] = (int64_t)slot;
-        // the creator of a class stores its tuple later (class_commit_kernel): one class
-        // (bits 40+) and n arena ids (bits 0-39), placed by a device-wide prefix sum
-        if (claimed) unit_claim[u] = (1ULL << 40) | (unsigned long long)b.unit_count[u];
+        if (touched) unit_slot[u] = where;
+        unit_claim[u] = claim;
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_unaligned) atomicAdd(t.n_unaligned, (unsigned long long)s_unaligned);
     if (!retry_deferred && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(t.n_units, (unsigned long long)b.n_units);
 }
@@ -254,11 +268,11 @@ class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets
     }
 }
 
-static inline unsigned grid_for(int64_t n)
+static inline unsigned grid_for(int64_t n, int64_t cap = 256 * 16)
 {
     int64_t blocks = (n + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > cap) blocks = cap;
     return (unsigned)blocks;
 }
 
@@ -273,7 +287,8 @@ void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_ba
                          hipStream_t stream)
 {
     if (b.n_units == 0) return;
-    hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
+    // (2048 blocks: one same-address atomic per block for the unaligned tally)
+    hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units, 2048)), dim3(256), 0, stream, t, b,
                        unit_base, unit_slot, unit_claim, retry_deferred);
 }
 
