@@ -72,6 +72,57 @@ def test_index_save_load_roundtrip(native_libs, tmp_path, chr21):
     assert loaded.transcripts['transcript_id'].tolist() == index.transcripts['transcript_id'].tolist()
 
 
+def test_index_load_maps_the_container(native_libs, tmp_path, chr21):
+    """The four big arrays come back as views of the file (no copy through the zip reader); a
+    deflated container, which cannot be mapped, still loads through numpy; a wrong version is
+    refused like the reference does (seekmer/_common.pyx:303-304)."""
+    from seekmer_amd import common, index_builder
+    index = index_builder.build(chr21[0][:40], chr21[1][:40])
+    path = tmp_path / 'index.npz'
+    index.save(path)
+    mapped = common._map_npz_members(str(path))
+    assert sorted(mapped) == sorted(ARRAYS)
+    for name in ARRAYS:
+        assert isinstance(mapped[name], np.memmap)
+        assert mapped[name].dtype == getattr(index, name).dtype
+        assert mapped[name].tobytes() == getattr(index, name).tobytes()
+    packed = tmp_path / 'deflated.npz'
+    np.savez_compressed(packed, seekmer_version=np.asarray(common._INDEX_VERSION),
+                        kmers=index.kmers, contigs=index.contigs, sequences=index.sequences,
+                        targets=index.targets, transcripts=np.asarray(index.transcripts),
+                        exons=np.asarray(index.exons))
+    assert common._map_npz_members(str(packed)) == {}
+    loaded = common.KMerIndex.load(packed)
+    for name in ARRAYS:
+        assert getattr(loaded, name).tobytes() == getattr(index, name).tobytes()
+    wrong = tmp_path / 'wrong.npz'
+    np.savez(wrong, seekmer_version=np.asarray('0.0.0'), kmers=index.kmers, contigs=index.contigs,
+             sequences=index.sequences, targets=index.targets,
+             transcripts=np.asarray(index.transcripts), exons=np.asarray(index.exons))
+    with pytest.raises(RuntimeError):
+        common.KMerIndex.load(wrong)
+
+
+def test_native_feeder_batches_outlive_the_loop(native_libs, tmp_path):
+    """Batches are views of slabs owned by the reader; one kept past the loop (and past the
+    reader) must stay intact, and slabs of dropped batches are reused."""
+    from seekmer_amd import common
+    lines = []
+    for i in range(5000):
+        lines += [b'@r%d\n' % i, b'ACGT' * 10 + b'%04d' % i + b'\n', b'+\n', b'I' * 44 + b'\n']
+    path = tmp_path / 'r.fastq'
+    path.write_bytes(b''.join(lines))
+    kept = []
+    for k, batch in enumerate(common.NativeReadFeeder([path], paired=False, batch_units=512)):
+        if k in (0, 3):
+            kept.append((k, batch))
+    for k, batch in kept:
+        reads = batch.reads
+        assert len(reads) == 512
+        assert reads[0] == b'ACGT' * 10 + b'%04d' % (512 * k) and reads[-1][-4:] == b'%04d' % (512 * k + 511)
+        assert batch.names[0] == b'r%d' % (512 * k)
+
+
 # ---- feeders: the reference's TestReadFeeder (seekmer/test/test_mapper.py:20-68)
 _BASE_SET = set(b'ACTGNactg')
 
