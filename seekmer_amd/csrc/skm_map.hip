@@ -54,6 +54,22 @@ __device__ __forceinline__ void pack_dword(uint32_t w, int first, int n, uint64_
     acgt |= flag_nibble << (28 - 4 * d);
 }
 
+// The same four bases when they are expected to be upper-case ACGT (nearly every word of a
+// FASTQ file): codes only, and `bad` collects anything that is not -- a word with bad == 0 has
+// the all-ones flag pattern and needs no more work; any other word is redone by pack_dword.
+__device__ __forceinline__ void pack_dword_plain(uint32_t w, int first, int n, uint64_t &codes, uint32_t &bad)
+{
+    const int cnt = n - first;
+    if (cnt <= 0) return;
+    const uint32_t keep = cnt >= 4 ? 0xffffffffu : ((1u << (8 * cnt)) - 1u);
+    const uint32_t idx = (w >> 1) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, idx);      // 'A','C','T','G' by idx
+    bad |= (w ^ expect) & keep;
+    const uint32_t code = (idx ^ ((idx >> 1) & 0x01010101u)) & keep;          // A0 C1 G2 T3
+    const uint32_t code_byte = (code * 0x40100401u) >> 24;                    // first base in the top bits
+    codes |= (uint64_t)code_byte << (56 - 8 * (first >> 2));
+}
+
 __global__ void __launch_bounds__(256)
 pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offsets,
                   int64_t n_reads, int words_per_read, int record_words, uint32_t *__restrict__ records)
@@ -77,10 +93,20 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
             if (at + 32 <= end_of_bases) {
                 const Bytes16 lo = *reinterpret_cast<const Bytes16 *>(bases + at);
                 const Bytes16 hi = *reinterpret_cast<const Bytes16 *>(bases + at + 16);
+                uint32_t bad = 0;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) pack_dword(lo.w[d], 4 * d, n, c, m);
+                for (int d = 0; d < 4; ++d) pack_dword_plain(lo.w[d], 4 * d, n, c, bad);
 #pragma unroll
-                for (int d = 0; d < 4; ++d) pack_dword(hi.w[d], 16 + 4 * d, n, c, m);
+                for (int d = 0; d < 4; ++d) pack_dword_plain(hi.w[d], 16 + 4 * d, n, c, bad);
+                if (bad == 0) {
+                    m = n >= 32 ? 0xffffffffu : ~(0xffffffffu >> n);      // n upper-case ACGT bases
+                } else {                                   // N, lower case, anything else: the full rule
+                    c = 0;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) pack_dword(lo.w[d], 4 * d, n, c, m);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) pack_dword(hi.w[d], 16 + 4 * d, n, c, m);
+                }
             } else {                                   // last bytes of the batch: stay in bounds
                 for (int i = 0; i < n; ++i) pack_byte(bases[at + i], i, c, m);
             }
