@@ -271,6 +271,10 @@ def main():
                 'classes': sizes[0], 'class_map_rows': sizes[1],
                 'em_iterations': int(state['iters']),
                 'em_iters_per_s': state['em']['iterations'] / (state['em']['em_ns'] * 1e-9),
+                # B_em = M*(4+8+16) + C*(4+8) + T*40 algorithmic bytes per EM step
+                'em_bytes_per_step': int(sizes[1] * 28 + sizes[0] * 12 + n_tx * 40),
+                'em_algorithmic_GBps': (sizes[1] * 28 + sizes[0] * 12 + n_tx * 40)
+                                       * state['em']['iterations'] / max(state['em']['em_ns'], 1.0),
                 'parallelism': 'reads sharded x%d, RCCL all-reduce f64[T] per EM step' % world,
                 'phase_ms': {'pack': pack_ns * 1e-6, 'map': map_ns * 1e-6, 'classes': class_ns * 1e-6,
                              'em': state['em']['em_ns'] * 1e-6},
