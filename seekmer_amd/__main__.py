@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""CLI (reference: seekmer/__main__.py:13-71): `seekmer_amd [--debug] {index,infer} ...`"""
+"""CLI (reference: seekmer/__main__.py:13-71): `seekmer_amd [--debug] {index,infer,impute} ...`"""
 import argparse
 import logging
 import sys
 
+from . import impute
 from . import index_builder
 from . import infer
 
@@ -16,6 +17,7 @@ def main(argv=None):
     subparsers = parser.add_subparsers(title='subcommand', dest='subcommand')
     index_builder.add_subcommand_parser(subparsers)
     infer.add_subcommand_parser(subparsers)
+    impute.add_subcommand_parser(subparsers)
     opts = vars(parser.parse_args(argv))
     logging.basicConfig(level=logging.DEBUG if opts['debug'] else logging.INFO,
                         format='%(levelname)-5s %(asctime)s %(name)s: %(message)s',
@@ -24,6 +26,8 @@ def main(argv=None):
         index_builder.run(**opts)
     elif opts['subcommand'] == 'infer':
         infer.run(**opts)
+    elif opts['subcommand'] == 'impute':
+        impute.run(**opts)
     else:
         parser.print_help()
     return 0

@@ -1150,6 +1150,42 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
 
 }  // namespace
 
+namespace {
+
+// numpy.sum of a contiguous f8 array on the host, bit for bit (blocks of 8192, pairwise inside;
+// see np_sum_blocks_kernel): n = class_count.sum() of infer.py:152 for counts that are not
+// integers (blended single-cell tables, impute.py:248-252)
+double np_pairwise_host(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int64_t i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_host(a, n2) + np_pairwise_host(a + n2, n - n2);
+}
+
+double np_sum_host(const double *a, int64_t n)
+{
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; i += 8192) acc += np_pairwise_host(a + i, std::min<int64_t>(8192, n - i));
+    return acc;
+}
+
+}  // namespace
+
 extern "C" int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
                                 const int64_t *class_offsets, const int32_t *class_targets,
                                 const double *class_counts, skm_quant **out)
@@ -1161,11 +1197,9 @@ extern "C" int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
     SKM_TRY(skm_device_count(&n_dev));
     if (device < 0 || device >= n_dev) return fail(SKM_ERR_ARG, "device %d out of range", device);
     const int64_t M = n_classes ? class_offsets[n_classes] - class_offsets[0] : 0;
-    double total = 0;
-    for (int64_t c = 0; c < n_classes; ++c) {
+    for (int64_t c = 0; c < n_classes; ++c)
         if (class_offsets[c + 1] < class_offsets[c]) return fail(SKM_ERR_ARG, "class offsets are not monotone");
-        total += class_counts[c];
-    }
+    const double total = np_sum_host(class_counts, n_classes);
     for (int64_t j = 0; j < M; ++j) {
         const int32_t t = class_targets[class_offsets[0] + j];
         if (t < 0 || t >= n_tx) return fail(SKM_ERR_ARG, "class target %d outside [0, n_tx)", t);
@@ -1329,8 +1363,7 @@ extern "C" int skm_quant_set_counts(skm_quant *q, const double *class_counts)
     if (!q || (!class_counts && q->n_classes)) return fail(SKM_ERR_ARG, "NULL argument");
     std::lock_guard<std::mutex> lock(q->mu);
     SKM_TRY(set_device(q->device));
-    double total = 0;
-    for (int64_t c = 0; c < q->n_classes; ++c) total += class_counts[c];
+    const double total = np_sum_host(class_counts, q->n_classes);
     if (q->n_classes) {
         // caller's class order -> internal (locality) order
         SKM_TRY(q->cls_count_saved.ensure(q->n_classes));

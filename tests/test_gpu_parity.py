@@ -457,6 +457,73 @@ def test_full_size_properties(oracle, native_libs):
     assert single.fragment_length_counts.sum() == 2 * n_units  # every read counted
 
 
+def test_impute_end_to_end(oracle, native_libs, tmp_path):
+    """`seekmer impute` (seekmer/impute.py:54-125) on five small cells of two expression
+    profiles: FASTQ files -> tpm.csv through the CLI, against the same pipeline spelled out on
+    the oracle (per-cell class tables, pooled histogram, first-round EM, weights, blended
+    counts, second-round EM).  The reference's own impute module cannot be run here (it imports
+    logbook): parity of this stage is unpinned beyond the restated arithmetic."""
+    import pandas
+    from seekmer_amd import synth, index_builder, common, impute
+    from seekmer_amd.__main__ import main
+    ids, pool, tx_offsets = synth.transcriptome(5, 30)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    transcripts = np.zeros(len(ids), dtype=[('transcript_id', index.transcripts.dtype['transcript_id']),
+                                            ('gene_id', 'S8'), ('length', 'f8')])
+    transcripts['transcript_id'] = index.transcripts['transcript_id']
+    transcripts['length'] = index.transcripts['length']
+    transcripts['gene_id'] = [b'GENE%04d' % (t // 4) for t in range(len(ids))]
+    index = common.KMerIndex(index.kmers, index.contigs, index.sequences, index.targets, transcripts,
+                             index.exons)
+    index_path = tmp_path / 'index.npz'
+    index.save(index_path)
+    oindex = oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                                lengths=np.diff(tx_offsets))
+    n_units, read_len, paths, cells = 6000, 75, [], []
+    for cell in range(5):
+        bases, offsets = synth.reads(100 + cell % 2, pool, tx_offsets, cell * n_units, n_units, read_len, True)
+        reads = bases[:-1].reshape(n_units, 2, read_len)
+        for mate in (0, 1):
+            path = tmp_path / ('cell%d_%d.fastq' % (cell, mate + 1))
+            path.write_bytes(b''.join(b'@c%d/%d\n%s\n+\n%s\n' % (i, mate + 1, reads[i, mate].tobytes(),
+                                                                  b'I' * read_len) for i in range(n_units)))
+            paths.append(path)
+        cells.append((bases, offsets))
+    out = tmp_path / 'out'
+    assert main(['impute', str(index_path), str(out), *map(str, paths), '-p', '4', '--seed', '0']) == 0
+    table = pandas.read_csv(out / 'tpm.csv', index_col=0)
+    assert table.shape == (len(ids), 5) and list(table.columns) == [str(p) for p in paths[::2]]
+
+    # the same on the oracle
+    fld_total = np.zeros(2000, dtype=np.int64)
+    tables = []
+    for bases, offsets in cells:
+        fld = np.zeros(2000, dtype=np.int64)
+        result = oracle.map_batch(oindex, bases, offsets, n_units, True, fld)
+        classes = oracle.Classes()
+        classes.update(result)
+        tables.append(classes.summarize())
+        fld_total += fld
+    eff = oracle.effective_lengths(fld_total, oindex.lengths)
+    base = np.asarray([oracle.quantify(eff, class_map, class_count)[0] for class_map, class_count in tables])
+    weight = impute.cell_weights(index, base, seed=0) ** 4
+    np.testing.assert_allclose(pandas.read_csv(out / 'weight.csv', index_col=0).to_numpy() ** 4, weight,
+                               rtol=1e-9, atol=0)
+    shifted, start = [], 0
+    for class_map, _ in tables:
+        shifted.append(np.vstack([class_map[0] + start, class_map[1]]))
+        start += int(class_map[0].max()) + 1
+    blended_map = np.concatenate(shifted, axis=1)
+    for cell in range(5):
+        total = tables[cell][1].sum()
+        counts = np.concatenate([c * w * total / c.sum() for (_, c), w in zip(tables, weight[cell])])
+        expected = oracle.quantify(eff, blended_map, counts)[0]
+        got = table.iloc[:, cell].to_numpy()
+        mask = expected > 0
+        np.testing.assert_array_equal(got > 0, mask)
+        assert (np.abs(got[mask] - expected[mask]) / expected[mask]).max() < 1e-4
+
+
 def test_baseline_config2_properties(oracle, native_libs):
     """BASELINE.json configs[1] at its full size -- the ~190k-transcript stand-in index
     (2 GiB k-mer table) and 10 M 2x100 pairs, where the oracle would need a minute per run --

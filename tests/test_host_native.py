@@ -207,3 +207,59 @@ def test_synth_is_deterministic_and_sliceable(native_libs):
     assert part[:-1].tobytes() == full[1234 * 150:(1234 + 100) * 150].tobytes()
     single, o = synth.reads(5, pool, offsets, 0, 10, 100, False)
     assert o.tolist() == list(range(0, 1001, 100))
+
+
+# ---- impute: the host-side arithmetic around the kernels (seekmer/impute.py:149-252)
+def test_impute_weights_and_blend(native_libs):
+    """gene_matrix / cell_weights / blend against the reference's formulae spelled out
+    naively: integer truncation of the gene sums, correlation + 2-means cut, and the
+    count blend c_j * w_ij * total_i / total_j over the concatenated class tables."""
+    import types
+    from seekmer_amd import impute
+    rng = np.random.default_rng(3)
+    n_tx, n_cells = 60, 5
+    transcripts = np.zeros(n_tx, dtype=[('transcript_id', 'S8'), ('gene_id', 'S6'), ('length', 'f8')])
+    transcripts['gene_id'] = [b'' if t % 11 == 0 else b'G%03d' % (t // 9 if t % 2 else 6 - t // 9) for t in range(n_tx)]
+    index = types.SimpleNamespace(transcripts=transcripts)
+    profile = rng.gamma(0.5, 200.0, size=(2, n_tx))
+    tpm = np.stack([profile[c % 2] * rng.uniform(0.5, 1.5, n_tx) for c in range(n_cells)])
+    matrix, genes = impute.gene_matrix(index, tpm)
+    all_genes, inverse = np.unique(transcripts['gene_id'], return_inverse=True)
+    expected = np.zeros((n_cells, len(all_genes)), dtype='i8')
+    for g in range(len(all_genes)):
+        expected[:, g] = tpm[:, inverse == g].sum(axis=1)
+    np.testing.assert_array_equal(matrix, expected[:, all_genes != b''])
+    assert genes.tolist() == all_genes[all_genes != b''].tolist()
+
+    weights = impute.cell_weights(index, tpm, seed=0)
+    corr = np.corrcoef(matrix)
+    assert weights.shape == (n_cells, n_cells)
+    kept = weights != 0
+    np.testing.assert_array_equal(weights[kept], corr[kept])      # kept values are the correlations
+    assert kept.diagonal().all()                                   # r = 1 sits in the upper cluster
+    off = corr[~np.eye(n_cells, dtype=bool)]
+    assert corr[kept].min() > off[~kept[~np.eye(n_cells, dtype=bool)]].max()   # a threshold cut
+
+    summaries = []
+    for c in range(n_cells):
+        n_classes = int(rng.integers(3, 8))
+        sizes = rng.integers(1, 4, n_classes)
+        class_map = np.vstack([np.repeat(np.arange(n_classes), sizes),
+                               rng.integers(0, n_tx, sizes.sum())]).astype(np.int64)
+        summaries.append(types.SimpleNamespace(class_map=class_map,
+                                               class_count=rng.integers(1, 50, n_classes).astype('f8')))
+    offsets, targets, counts = impute.blend(summaries, weights ** 3)
+    assert offsets[-1] == targets.size == sum(s.class_map.shape[1] for s in summaries)
+    np.testing.assert_array_equal(targets, np.concatenate([s.class_map[1] for s in summaries]))
+    np.testing.assert_array_equal(np.diff(offsets),
+                                  np.concatenate([np.bincount(s.class_map[0]) for s in summaries]))
+    w = weights ** 3
+    for i in range(n_cells):
+        total_i = summaries[i].class_count.sum()
+        naive = np.concatenate([s.class_count * w[i, j] * total_i / s.class_count.sum()
+                                for j, s in enumerate(summaries)])
+        np.testing.assert_array_equal(counts[i], naive)
+    with pytest.raises(ValueError):
+        impute.blend(summaries + [types.SimpleNamespace(class_map=np.zeros((2, 0), np.int64),
+                                                        class_count=np.zeros(0))], np.ones((6, 6)))
+
