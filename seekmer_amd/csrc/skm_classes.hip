@@ -244,9 +244,30 @@ class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets
         bool claimed;
         const uint64_t slot = probe_claim(t, key, claimed, ~0ULL);
         if (slot == ~0ULL) { atomicExch(t.error, SKM_ERR_STATE); continue; }
+        // the wave's new classes take their registry entries and arena space with one atomic
+        // per counter (same-address atomics serialise: three per class were 30 ms per million)
+        const unsigned long long makers = __ballot(claimed);
+        long long a = 0, k = 0;
+        if (makers) {
+            const int lane = (int)(threadIdx.x & 63);
+            int before = 0, total = 0;
+            for (unsigned long long m = makers; m; m &= m - 1) {
+                const int src = __builtin_ctzll(m);
+                const int v = __builtin_amdgcn_readlane(n, src);
+                if (src < lane) before += v;
+                total += v;
+            }
+            const int leader = __builtin_ctzll(makers);
+            unsigned long long base_a = 0, base_k = 0;
+            if (lane == leader) {
+                base_a = atomicAdd(t.arena_cursor, (unsigned long long)total);
+                base_k = atomicAdd(t.n_listed, (unsigned long long)__popcll(makers));
+                atomicAdd(t.n_classes, (unsigned long long)__popcll(makers));
+            }
+            a = (long long)__shfl(base_a, leader, 64) + before;
+            k = (long long)__shfl(base_k, leader, 64) + __popcll(makers & ((1ULL << lane) - 1));
+        }
         if (claimed) {
-            const long long a = (long long)atomicAdd(t.arena_cursor, (unsigned long long)n);
-            const long long k = (long long)atomicAdd(t.n_listed, 1ULL);
             if (a + n > t.arena_capacity || k >= t.class_list_capacity) {
                 atomicExch(t.error, SKM_ERR_STATE);
                 continue;
@@ -254,7 +275,6 @@ class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets
             for (int i = 0; i < n; ++i) t.arena[a + i] = class_targets[off + i];
             t.slots[slot].tuple = tuple_pack(a, n);
             t.class_list[k] = (int64_t)slot;
-            atomicAdd(t.n_classes, 1ULL);
         } else {
             // classes of the resident table are all committed between batches
             const long long stored = t.slots[slot].tuple;
