@@ -255,6 +255,35 @@ def test_quantify_resident_matches_host_path(oracle, native_libs):
     assert (np.abs(tpm_dev[mask] - tpm_ref[mask]) / tpm_ref[mask]).max() < 1e-4
 
 
+@pytest.mark.parametrize('paired', [True, False])
+def test_access_counters_equal_the_oracles(oracle, native_libs, chr21, chr21_oracle_index, paired):
+    """The counting build of the map kernel (map_units_kernel<true>) performs the reference's
+    access pattern and tallies it; its counters are what bench.py turns into algorithmic bytes
+    (B_map), so they must equal the oracle's, field by field -- and the results of
+    the counting build must be the production build's."""
+    from seekmer_amd import mapper, common
+    rng = np.random.default_rng(37)
+    reads = _adversarial_reads(chr21[1], rng, 5000, 100)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = len(reads) // 2 if paired else len(reads)
+    fld = np.zeros(2000, dtype=np.int64)
+    ostats = oracle.Stats()
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld, stats=ostats)
+    result = mapper.MapResult(index)
+    result.set_stats(True)
+    rm = mapper.ReadMapper(index, result)
+    rm.map_batch(common.ReadBatch(n_units, bases, offsets, paired))
+    _compare_units(expected, rm.last_batch(n_units))
+    _compare_tables(oracle, expected, fld, result)
+    counted = result.access_stats()
+    for name, value in ostats.as_dict().items():
+        assert counted[name] == value, (name, counted[name], value)
+    assert (counted['read_bases'] + 16 * counted['slots'] + 48 * counted['contig_reads']
+            + 8 * (counted['targets_copied'] + counted['targets_merged']) + 8 * counted['seq_fetches']
+            + 4 * counted['tuple_ids']) == ostats.algorithmic_bytes()
+
+
 def test_batches_accumulate(oracle, native_libs, chr21, chr21_oracle_index):
     """Several batches into one MapResult == one big batch (first-seen order kept)."""
     from seekmer_amd import mapper, common
