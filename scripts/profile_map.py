@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--single', action='store_true')
     ap.add_argument('--cache', default='')
     ap.add_argument('--stats', action='store_true')
+    ap.add_argument('--again', action='store_true', help='map the batch once more without a reset')
     ap.add_argument('--sorted', action='store_true',
                     help='experiment: re-run with the units ordered by their anchor contig')
     args = ap.parse_args()
@@ -60,6 +61,13 @@ def main():
         print('rep %d: wall %.2f ms pack %.3f map %.3f classes %.3f ms sizes %s' % (
             rep, wall * 1e3, (after['pack_ns'] - before['pack_ns']) * 1e-6,
             (after['map_ns'] - before['map_ns']) * 1e-6,
+            (after['class_ns'] - before['class_ns']) * 1e-6, result.sizes()), flush=True)
+    if args.again:          # the same batch once more WITHOUT a reset: every class exists already
+        before = result.timing()
+        result.map_resident(d_bases, d_off, args.pairs, paired, args.read_len)
+        after = result.timing()
+        print('again (no reset): pack %.3f map %.3f classes %.3f ms sizes %s' % (
+            (after['pack_ns'] - before['pack_ns']) * 1e-6, (after['map_ns'] - before['map_ns']) * 1e-6,
             (after['class_ns'] - before['class_ns']) * 1e-6, result.sizes()), flush=True)
     if args.stats:
         print(result.access_stats())
