@@ -237,10 +237,10 @@ def main():
     achieved = algorithmic / map_ns if map_ns else 0.0          # bytes/ns = GB/s
     sizes = result.sizes()
     # HBM traffic of the same launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, rocprofv3,
-    # separate --pmc runs, profiles/r01_h_pmc_map.json); only quoted for the workload it was taken on
+    # separate --pmc runs, profiles/r01_i_pmc_map.json); only quoted for the workload it was taken on
     traffic, miss_rate = None, None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_h_pmc_map.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r01_i_pmc_map.json')) as f:
             pmc = json.load(f)
         if args.genes == 20000 and n_units == 10_000_000 and args.read_len == 100:
             traffic = pmc['derived']['hbm_traffic_bytes']
