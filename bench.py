@@ -127,6 +127,8 @@ def main():
     from seekmer_amd import _native, index_builder, infer, mapper, synth
     hip = _native.hip()
     device = local_rank
+    if os.environ.get('SKM_BENCH_ONE_DEVICE') == '1':      # rehearsal of the N > 1 path on a 1-GPU box
+        device = 0
     if _native.device_count() <= device:
         raise SystemExit('no GPU %d visible: the benchmark has no CPU path' % device)
 
