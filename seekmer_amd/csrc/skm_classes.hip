@@ -53,9 +53,9 @@ __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned lo
     claimed = false;
     if (limit > t.slot_mask + 1) limit = t.slot_mask + 1;
     for (uint64_t n = 0; n < limit; ++n) {
-        const ClassSlot *s = &t.slots[slot];
-        unsigned long long cur = s->key;
-        if (seen) *seen = s->first_seen;
+        const ulonglong2 head = *reinterpret_cast<const ulonglong2 *>(&t.slots[slot]);   // key, first_seen
+        unsigned long long cur = head.x;
+        if (seen) *seen = head.y;
         if (cur == 0) {
             cur = atomicCAS(&t.slots[slot].key, 0ULL, key);
             if (cur == 0) { claimed = true; return slot; }

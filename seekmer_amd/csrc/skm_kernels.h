@@ -51,10 +51,10 @@ void launch_gather_probe(const void *table, uint64_t n_slots, int blocks, int pe
                          unsigned long long *sink, hipStream_t stream);
 
 // ---- equivalence-class table (skm_classes.hip)
-struct ClassSlot {                // 32 B
+struct alignas(32) ClassSlot {    // 32 B; key and first_seen side by side: one 16-byte load per probe
     unsigned long long key;       // 0 = empty
-    unsigned long long count;
     unsigned long long first_seen;  // global unit index of the first unit of the class
+    unsigned long long count;
     long long tuple;              // -1 until the tuple has been committed to the arena, then
                                   // arena offset (bits 0-39) | tuple length (bits 40-62)
 };
