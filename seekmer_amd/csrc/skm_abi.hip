@@ -123,6 +123,7 @@ struct skm_mapper {
     DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
     int grid_blocks = 0;
     int64_t units_done = 0;
+    int64_t first_seen_bound = 0;     // every first_seen in the table is below this
     int64_t last_units = 0, last_ids = 0;
     int64_t host_classes = 0, host_arena_used = 0;
     bool want_stats = false;
@@ -439,6 +440,7 @@ int table_reset(skm_mapper *m, uint64_t n_slots)
     m->host_classes = 0;
     m->host_arena_used = 0;
     m->units_done = 0;
+    m->first_seen_bound = 0;
     return SKM_OK;
 }
 
@@ -630,6 +632,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     if ((uint64_t)m->host_classes * 2 > m->t.slot_mask + 1)
         SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 2, 0));
     m->units_done += n_units;
+    m->first_seen_bound = std::max(m->first_seen_bound, m->units_done);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->t_pack_ns += ms * 1e6;
     HIP_TRY(hipEventElapsedTime(&ms, m->ev[1], m->ev[2])); m->t_map_ns += ms * 1e6;
@@ -871,6 +874,9 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
         m->host_classes = (int64_t)ctr[CTR_CLASSES];
     }
     m->units_done += units;
+    for (int64_t c = 0; c < n_classes; ++c)
+        m->first_seen_bound = std::max(m->first_seen_bound, first_seen[c] + 1);
+    m->first_seen_bound = std::max(m->first_seen_bound, m->units_done);
     return SKM_OK;
 }
 
@@ -1003,9 +1009,14 @@ QuantBuild quant_build_view(skm_quant *q)
     return b;
 }
 
-int quant_finish_setup(skm_quant *q, const ClassTable *table)
+int quant_finish_setup(skm_quant *q, const ClassTable *table, int64_t units_seen = -1)
 {
     QuantBuild b = quant_build_view(q);
+    b.first_seen_bits = 64;
+    if (units_seen >= 0) {                       // first-seen values are unit indices below this
+        b.first_seen_bits = 1;
+        while (b.first_seen_bits < 63 && (1LL << b.first_seen_bits) <= units_seen) ++b.first_seen_bits;
+    }
     const int64_t rows = quant_setup(table, b, q->perm.p, q->stream);
     if (rows < 0) return fail(SKM_ERR_HIP, "building the class views failed (%lld): %s",
                               (long long)rows, hipGetErrorString(hipGetLastError()));
@@ -1234,7 +1245,7 @@ extern "C" int skm_quant_create_from_mapper(skm_mapper *m, int64_t n_tx, skm_qua
     unsigned long long ctr[4];
     HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));
     q->n_total = (double)(ctr[CTR_UNITS] - ctr[CTR_UNALIGNED]);
-    rc = quant_finish_setup(q, &m->t);
+    rc = quant_finish_setup(q, &m->t, m->first_seen_bound);
     if (rc != SKM_OK) { skm_quant_destroy(q); return rc; }
     *out = q;
     return SKM_OK;
@@ -1298,7 +1309,7 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         launch_np_sum(q->x0.p, n_tx, 1.0, sums.p, total, q->stream);
         launch_divide(q->x0.p, n_tx, total, false, 0.0, q->stream);
         lap("start vector");
-        SKM_TRY(quant_finish_setup(q, &m->t));
+        SKM_TRY(quant_finish_setup(q, &m->t, m->first_seen_bound));
         lap("setup");
         int64_t it = 0;
         SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, &it));

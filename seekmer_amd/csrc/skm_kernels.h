@@ -148,6 +148,7 @@ struct QuantBuild {
     int64_t *row_start;           // [R+1] out (capacity n_rows_cap + 1)
     int32_t *row_tx;              // [R]   out
     int64_t n_rows_cap;
+    int first_seen_bits;          // significant bits of the table's first-seen values (sort width)
 };
 // One asynchronous pipeline: (classes from a mapper's table in first-seen order when `table` is
 // given) -> stable reorder by smallest transcript id (gather locality; perm[k] = caller's index of

@@ -258,7 +258,8 @@ int build_from_table(Scratch &scratch, const ClassTable &t, QuantBuild &q)
     hipLaunchKernelGGL(table_dump_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream,
                        t, n_classes, arena_off, len, count, first);
     hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, iota, n_classes);
-    if (sort_pairs(scratch, first, first_sorted, iota, perm, n_classes, 64)) return -1;
+    const int first_bits = q.first_seen_bits > 0 && q.first_seen_bits < 64 ? q.first_seen_bits : 64;
+    if (sort_pairs(scratch, first, first_sorted, iota, perm, n_classes, first_bits)) return -1;
     hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm,
                        n_classes, len, count, len_sorted, q.cls_count);
     if (exclusive_scan_with_total(scratch, len_sorted, q.cls_offset, n_classes)) return -1;
