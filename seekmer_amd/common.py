@@ -350,6 +350,7 @@ class NativeReadFeeder:
         tools = {'.gz': 'zcat', '.bz2': 'bzcat', '.xz': 'xzcat', '.lzma': 'xzcat'}
         processes, names = [], []
         host = _native.host()
+        reader = None
         try:
             for path in self.paths:
                 if path.suffix in tools:
@@ -388,6 +389,14 @@ class NativeReadFeeder:
                 yield batch
                 del batch, owner, bases, offsets, name_bytes, name_offsets, view
         finally:
+            # The native reader holds its own descriptors of the decompressors' pipes
+            # (/dev/fd/N): close them first, or a zcat blocked on a full pipe never sees
+            # SIGPIPE and wait() below never returns (early exit from the loop, an error
+            # while mapping).
+            if reader is not None:
+                reader.close()
             for process in processes:
                 process.stdout.close()
+                if process.poll() is None:
+                    process.terminate()
                 process.wait()

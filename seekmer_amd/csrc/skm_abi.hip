@@ -78,6 +78,18 @@ struct DBuf {
     size_t bytes() const { return cap * sizeof(T); }
 };
 
+// runs a clean-up on every exit of the enclosing scope unless dismissed (the HIP_TRY / SKM_TRY
+// macros return from the middle of a function)
+template <class F>
+struct ScopeGuard {
+    F f;
+    bool armed = true;
+    explicit ScopeGuard(F fn) : f(fn) {}
+    ~ScopeGuard() { if (armed) f(); }
+    void dismiss() { armed = false; }
+};
+template <class F> ScopeGuard<F> on_exit(F f) { return ScopeGuard<F>(f); }
+
 int set_device(int device)
 {
     HIP_TRY(hipSetDevice(device));
@@ -148,6 +160,7 @@ struct skm_quant {
     DBuf<unsigned int> part_flags;
     DBuf<unsigned long long> ctl, cum, draw;
     double n_total = 0;
+    bool n_total_reduced = false;             // n_total already is the sum over all ranks
     // RCCL communicator (borrowed from an skm_comm), loaded lazily
     void *comm = nullptr;
     int rank = 0, world = 1;
@@ -331,18 +344,22 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
 
     skm_index *ix = new skm_index();
     ix->device = device;
+    char *d_ascii = nullptr;
+    void *d_contigs48 = nullptr;
+    auto undo = on_exit([&]() {                 // any early return below: nothing is left behind
+        (void)hipFree(d_ascii); (void)hipFree(d_contigs48);
+        skm_index_destroy(ix);
+    });
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     ix->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int64_t n_words = (n_bases + 31) / 32 + 1;
-    char *d_ascii = nullptr;
     HIP_TRY(hipMalloc(&ix->kmers, (size_t)n_slots * sizeof(IndexEntry)));
     HIP_TRY(hipMalloc(&ix->contigs, (size_t)n_contigs * sizeof(DevContig)));
     HIP_TRY(hipMalloc(&ix->targets, (size_t)std::max<int64_t>(n_targets, 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ix->seq2, (size_t)n_words * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&d_ascii, (size_t)n_bases));
     HIP_TRY(hipMemcpy(ix->kmers, kmers, (size_t)n_slots * sizeof(IndexEntry), hipMemcpyHostToDevice));
-    void *d_contigs48 = nullptr;
     HIP_TRY(hipMalloc(&d_contigs48, (size_t)n_contigs * sizeof(ContigEntry)));
     HIP_TRY(hipMemcpy(d_contigs48, contigs, (size_t)n_contigs * sizeof(ContigEntry), hipMemcpyHostToDevice));
     launch_pack_contigs(d_contigs48, n_contigs, ix->contigs, nullptr);
@@ -357,7 +374,10 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(d_ascii));
+    d_ascii = nullptr;
     HIP_TRY(hipFree(d_contigs48));
+    d_contigs48 = nullptr;
+    undo.dismiss();
     ix->n_slots = n_slots;
     ix->d.kmers = (const IndexEntry *)ix->kmers;
     ix->d.slot_mask = (uint32_t)(n_slots - 1);
@@ -455,6 +475,7 @@ int table_grow(skm_mapper *m, uint64_t want_slots, int64_t units_in_flight)
     if (need == n_slots) return SKM_OK;
     DBuf<ClassSlot> new_slots;
     DBuf<int64_t> forward;
+    auto undo = on_exit([&]() { new_slots.release(); forward.release(); });
     SKM_TRY(new_slots.ensure(need));
     SKM_TRY(forward.ensure(n_slots));
     ClassTable to = m->t;
@@ -472,6 +493,7 @@ int table_grow(skm_mapper *m, uint64_t want_slots, int64_t units_in_flight)
     m->slots.release();
     forward.release();
     m->slots = new_slots;
+    undo.dismiss();
     bind_table(m, need);
     return SKM_OK;
 }
@@ -796,6 +818,7 @@ extern "C" int skm_mapper_export(skm_mapper *m, int64_t *class_offsets, int32_t 
     if (class_offsets) class_offsets[0] = 0;
     if (C == 0) return SKM_OK;
     DBuf<int64_t> d_off, d_len; DBuf<double> d_cnt; DBuf<unsigned long long> d_fs;
+    auto undo = on_exit([&]() { d_off.release(); d_len.release(); d_cnt.release(); d_fs.release(); });
     SKM_TRY(d_off.ensure(C)); SKM_TRY(d_len.ensure(C)); SKM_TRY(d_cnt.ensure(C)); SKM_TRY(d_fs.ensure(C));
     launch_class_compact(m->t, C, d_off.p, d_len.p, d_cnt.p, d_fs.p, m->stream);
     HIP_TRY(hipGetLastError());
@@ -809,7 +832,6 @@ extern "C" int skm_mapper_export(skm_mapper *m, int64_t *class_offsets, int32_t 
     HIP_TRY(hipMemcpyAsync(fs.data(), d_fs.p, C * 8, hipMemcpyDeviceToHost, m->stream));
     if (M) HIP_TRY(hipMemcpyAsync(arena.data(), m->arena.p, (size_t)M * 4, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    d_off.release(); d_len.release(); d_cnt.release(); d_fs.release();
     // Counter insertion order under -j1 = ascending first-seen unit (mapper.py:88)
     std::vector<int64_t> order(C);
     std::iota(order.begin(), order.end(), 0);
@@ -842,10 +864,6 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
     add[CTR_UNALIGNED] = (unsigned long long)unaligned;
     add[CTR_UNITS] = (unsigned long long)units;
     if (fld) for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) add[CTR_FLD + i] = (unsigned long long)fld[i];
-    std::vector<unsigned long long> cur(CTR_WORDS);
-    HIP_TRY(hipMemcpy(cur.data(), m->counters.p, CTR_WORDS * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < CTR_WORDS; ++i) cur[i] += add[i];
-    HIP_TRY(hipMemcpy(m->counters.p, cur.data(), CTR_WORDS * 8, hipMemcpyHostToDevice));
     if (n_classes) {
         const int64_t M = class_offsets[n_classes];
         {   // foreign classes may all be new: size for them at load <= 0.5, unbounded probes
@@ -857,6 +875,7 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
         SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + M + 1024), true, m->stream));
         bind_table(m, m->t.slot_mask + 1);
         DBuf<int64_t> d_off, d_cnt, d_fs; DBuf<int32_t> d_ids;
+        auto undo = on_exit([&]() { d_off.release(); d_cnt.release(); d_fs.release(); d_ids.release(); });
         SKM_TRY(d_off.ensure(n_classes + 1)); SKM_TRY(d_cnt.ensure(n_classes));
         SKM_TRY(d_fs.ensure(n_classes)); SKM_TRY(d_ids.ensure(std::max<int64_t>(M, 1)));
         HIP_TRY(hipMemcpy(d_off.p, class_offsets, (n_classes + 1) * 8, hipMemcpyHostToDevice));
@@ -867,12 +886,15 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
         HIP_TRY(hipGetLastError());
         unsigned long long ctr[8];
         HIP_TRY(hipMemcpyAsync(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost, m->stream));
-        int rc = read_error(m);
-        d_off.release(); d_cnt.release(); d_fs.release(); d_ids.release();
-        if (rc != SKM_OK) return rc;
+        SKM_TRY(read_error(m));
         m->host_arena_used = (int64_t)ctr[CTR_ARENA];
         m->host_classes = (int64_t)ctr[CTR_CLASSES];
     }
+    // totals and histogram only once the classes are in: a failed merge leaves them untouched
+    std::vector<unsigned long long> cur(CTR_WORDS);
+    HIP_TRY(hipMemcpy(cur.data(), m->counters.p, CTR_WORDS * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < CTR_WORDS; ++i) cur[i] += add[i];
+    HIP_TRY(hipMemcpy(m->counters.p, cur.data(), CTR_WORDS * 8, hipMemcpyHostToDevice));
     m->units_done += units;
     for (int64_t c = 0; c < n_classes; ++c)
         m->first_seen_bound = std::max(m->first_seen_bound, first_seen[c] + 1);
@@ -1102,7 +1124,7 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
 {
     // n = class_count.sum() over ALL ranks (infer.py:152)
     double n_total = q->n_total;
-    if (q->comm) {
+    if (q->comm && !q->n_total_reduced) {
         HIP_TRY(hipMemcpyAsync(q->acc.p, &n_total, 8, hipMemcpyHostToDevice, q->stream));
         NCCL_TRY(g_rccl.AllReduce(q->acc.p, q->acc.p, 1, NCCL_FLOAT64, NCCL_SUM, q->comm, q->stream));
         HIP_TRY(hipMemcpyAsync(&n_total, q->acc.p, 8, hipMemcpyDeviceToHost, q->stream));
@@ -1284,22 +1306,37 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
     DBuf<double> sums;
     const int64_t n_blocks = (n_tx + 8191) / 8192;
     auto body = [&]() -> int {
-        SKM_TRY(fld.ensure(MAX_FRAGMENT_LENGTH));
+        SKM_TRY(fld.ensure(MAX_FRAGMENT_LENGTH + 1));
         SKM_TRY(sums.ensure(n_blocks + 2));
         double *const total = sums.p + n_blocks;          // [0] sum, [1] sum / divisor
         unsigned long long ctr[4];
         HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));   // (mapper stream is idle)
-        q->n_total = (double)(ctr[CTR_UNITS] - ctr[CTR_UNALIGNED]);
+        unsigned long long aligned = ctr[CTR_UNITS] - ctr[CTR_UNALIGNED];
         HIP_TRY(hipMemcpyAsync(fld.p, m->counters.p + CTR_FLD, MAX_FRAGMENT_LENGTH * 8,
                                hipMemcpyDeviceToDevice, q->stream));
-        if (q->comm)                                       // merge_fragment_lengths over the ranks
-            NCCL_TRY(g_rccl.AllReduce(fld.p, fld.p, MAX_FRAGMENT_LENGTH, NCCL_UINT64, NCCL_SUM, q->comm,
+        if (q->comm) {
+            // merge_fragment_lengths over the ranks, and with it (word 2000 of the same
+            // collective) n = class_count.sum() of infer.py:152 over ALL ranks.  Whether there
+            // is anything to quantify (infer.py:106-107 tests the merged table) must be decided
+            // on the global sum: a rank whose shard produced no class still has to take part
+            // in every collective of the EM below, with empty class views.
+            q->pinned[32] = aligned;
+            HIP_TRY(hipMemcpyAsync(fld.p + MAX_FRAGMENT_LENGTH, q->pinned + 32, 8, hipMemcpyHostToDevice, q->stream));
+            NCCL_TRY(g_rccl.AllReduce(fld.p, fld.p, MAX_FRAGMENT_LENGTH + 1, NCCL_UINT64, NCCL_SUM, q->comm,
                                       q->stream));
+            HIP_TRY(hipMemcpyAsync(q->pinned + 32, fld.p + MAX_FRAGMENT_LENGTH, 8, hipMemcpyDeviceToHost, q->stream));
+            HIP_TRY(hipStreamSynchronize(q->stream));
+            aligned = q->pinned[32];
+            q->n_total_reduced = true;
+        }
+        q->n_total = (double)aligned;
         HIP_TRY(hipMemcpyAsync(q->x1.p, lengths, n_tx * 8, hipMemcpyHostToDevice, q->stream));
         launch_effective_lengths(fld.p, q->x1.p, n_tx, q->eff_len.p, q->stream);
         if (effective_lengths)
             HIP_TRY(hipMemcpyAsync(effective_lengths, q->eff_len.p, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
-        if (C == 0) {                                      // quantify(): no class -> zeros (infer.py:100-101)
+        // quantify(): no class -> zeros (infer.py:106-107); over several ranks "no class anywhere"
+        // is "no aligned unit anywhere" (every aligned unit belongs to a class)
+        if (q->comm ? aligned == 0 : C == 0) {
             HIP_TRY(hipStreamSynchronize(q->stream));
             if (tpm) memset(tpm, 0, (size_t)n_tx * 8);
             if (iters) *iters = 0;
@@ -1412,6 +1449,11 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
     const double saved_total = q->n_total;
     const int64_t n_draws = (int64_t)run;            // n = class_count.sum(), infer.py:109
     int rc = SKM_OK;
+    auto restore = on_exit([&]() {                   // every exit: the handle holds the observed counts again
+        (void)hipMemcpyAsync(q->cls_count.p, q->cls_count_saved.p, C * 8, hipMemcpyDeviceToDevice, q->stream);
+        (void)hipStreamSynchronize(q->stream);
+        q->n_total = saved_total;
+    });
     for (int64_t b = 0; b < n_boot && rc == SKM_OK; ++b) {
         HIP_TRY(hipMemsetAsync(q->draw.p, 0, C * 8, q->stream));
         launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)b + (uint64_t)q->rank * 0x100000000ULL,
@@ -1435,9 +1477,6 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
         HIP_TRY(hipMemcpy(out + b * q->n_tx, (it & 1) ? q->x1.p : q->x0.p, q->n_tx * 8, hipMemcpyDeviceToHost));
         if (iters_out) iters_out[b] = it;
     }
-    HIP_TRY(hipMemcpyAsync(q->cls_count.p, q->cls_count_saved.p, C * 8, hipMemcpyDeviceToDevice, q->stream));
-    HIP_TRY(hipStreamSynchronize(q->stream));
-    q->n_total = saved_total;
     return rc;
 }
 

@@ -309,27 +309,48 @@ class ReadMapper:
                 self.map_result._write_readmap(batch.names, tuples)
 
 
+def _drain_worker(mapper, reads_queue, errors):
+    """Thread body of map_reads: run the mapper over the queue; on a failure (device error,
+    tag collision, bad batch) remember the first exception and keep taking batches up to the
+    sentinel so the feeding thread never blocks on a full queue."""
+    batches = iter(reads_queue.get, None)
+    try:
+        mapper(batches)
+    except BaseException as error:        # noqa: B902 -- re-raised by map_reads in the caller's thread
+        errors.append(error)
+        for __ in batches:
+            pass
+
+
 def map_reads(index, read_feeder, job_count=1, readmap=None, debug=False, device=0):
-    """Map reads (seekmer/mapper.py:148-193)."""
+    """Map reads (seekmer/mapper.py:148-193).  Unlike the reference's CPU workers the device
+    calls can fail; a worker's exception is re-raised here once every thread has stopped,
+    instead of being lost with its thread."""
     map_result = MapResult(index, readmap, device=device)
     try:
         if debug or job_count <= 1:
             ReadMapper(index, map_result)(read_feeder)
         else:
             reads_queue = queue.Queue(job_count * 2)
-            threads = []
+            threads, errors = [], []
             for __ in range(job_count):
-                thread = threading.Thread(target=ReadMapper(index, map_result),
-                                          args=(iter(reads_queue.get, None),))
+                thread = threading.Thread(target=_drain_worker,
+                                          args=(ReadMapper(index, map_result), reads_queue, errors))
                 threads.append(thread)
                 thread.start()
-            for batch in read_feeder:
-                reads_queue.put(batch)
-            for __ in range(job_count):
-                reads_queue.put(None)
-            for thread in threads:
-                thread.join()
-            threads.clear()
+            try:
+                for batch in read_feeder:
+                    if errors:
+                        break
+                    reads_queue.put(batch)
+            finally:
+                for __ in range(job_count):
+                    reads_queue.put(None)
+                for thread in threads:
+                    thread.join()
+                threads.clear()
+            if errors:
+                raise errors[0]
     finally:
         if readmap is not None:
             readmap.close()
@@ -337,7 +358,7 @@ def map_reads(index, read_feeder, job_count=1, readmap=None, debug=False, device
 
 
 def map_multiple_samples(index, read_feeders, job_count=1, debug=False, device=0):
-    """Map reads for multiple samples (seekmer/mapper.py:196-234)."""
+    """Map reads for multiple samples (seekmer/mapper.py:196-234); a failed sample raises."""
     map_results = []
     if debug:
         for read_feeder in read_feeders:
@@ -346,12 +367,15 @@ def map_multiple_samples(index, read_feeders, job_count=1, debug=False, device=0
             ReadMapper(index, result)(read_feeder)
     else:
         pool = multiprocessing.pool.ThreadPool(job_count)
+        pending = []
         for read_feeder in read_feeders:
             result = MapResult(index, device=device)
             map_results.append(result)
-            pool.apply_async(_map, args=(index, result, read_feeder))
+            pending.append(pool.apply_async(_map, args=(index, result, read_feeder)))
         pool.close()
         pool.join()
+        for job in pending:
+            job.get()                     # re-raises what the worker raised
     return map_results
 
 
