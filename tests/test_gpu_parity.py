@@ -169,6 +169,40 @@ def test_unsorted_target_slices_take_the_walks(oracle, native_libs, chr21, chr21
     _compare_tables(oracle, expected, fld, result)
 
 
+@pytest.mark.parametrize('paired', [True, False])
+def test_unassigned_slots_are_misses(oracle, native_libs, chr21, chr21_oracle_index, paired):
+    """An occupied slot whose position has offset < 0 is a miss for every caller
+    (_mapper.pyx:203, 211; _common.pyx:84-97).  No built index holds one
+    (tests/test_host_native.py::test_builder_never_leaves_an_occupied_slot_unassigned), so
+    the branch is driven with a tampered table: a tenth of the occupied slots lose their
+    position in three shapes -- the invalid coordinate (0, -1), the entry kept with offset -1,
+    and the complement of the real offset."""
+    rng = np.random.default_rng(41)
+    reads = _adversarial_reads(chr21[1], rng, 6000, 100)
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = len(reads) // 2 if paired else len(reads)
+    kmers = chr21_oracle_index.kmers.copy()
+    occupied = np.flatnonzero(kmers['kmer'] != np.uint64(0xFFFFFFFFFFFFFFFF))
+    chosen = rng.choice(occupied, occupied.size // 10, replace=False)
+    a, b, c = np.array_split(chosen, 3)
+    kmers['entry'][a] = 0
+    kmers['offset'][a] = -1
+    kmers['offset'][b] = -1
+    kmers['offset'][c] = ~kmers['offset'][c]
+    assert (kmers['offset'][chosen] < 0).all()
+    tampered = oracle.OracleIndex(kmers, chr21_oracle_index.contigs, chr21_oracle_index.sequences,
+                                  chr21_oracle_index.targets, lengths=chr21_oracle_index.lengths)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(tampered, bases, offsets, n_units, paired, fld)
+    fld_clean = np.zeros(2000, dtype=np.int64)
+    clean = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld_clean)
+    changed = (expected.begin != clean.begin) | (expected.end != clean.end) | (expected.count != clean.count)
+    assert changed.sum() > n_units // 20              # the branch decides a good share of the units
+    result, units = _run_gpu(make_product_index(tampered, chr21[0]), bases, offsets, n_units, paired)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_quantify_resident_without_classes(oracle, native_libs, chr21, chr21_oracle_index):
     """Nothing mapped: quantify() returns zeros (seekmer/infer.py:106-107), no EM step."""
     from seekmer_amd import infer
@@ -361,6 +395,39 @@ def test_em_skewed_and_degenerate_tables(oracle, native_libs):
     np.testing.assert_allclose(x_perm, x_ref2, rtol=1e-9, atol=1e-300)
 
 
+def _check_multinomial_dispersion(counts, class_count):
+    """Second moments of B draws of multinomial(n, p = class_count / n) (mean AND
+    variance): per class the sample variance over the replicates against n p (1 - p), and
+    Pearson's statistic sum_c (x_c - n p_c)^2 / (n p_c) of every replicate, which is
+    chi-square with C' - 1 degrees of freedom (C' = classes with p > 0).  Bounds are 6 sigma of
+    the respective sampling distributions, so a correct generator fails with p < 1e-8."""
+    counts = np.asarray(counts, dtype='f8')
+    n_boot = counts.shape[0]
+    n = class_count.sum()
+    p = class_count / n
+    live = p > 0
+    assert (counts[:, ~live] == 0).all()
+    var = counts[:, live].var(axis=0, ddof=1)
+    expect = n * p[live] * (1 - p[live])
+    big = expect > 25                                  # near-normal cells: var * (B-1) / expect ~ chi2(B-1)
+    ratio = var[big] / expect[big]
+    tol = 6 * np.sqrt(2.0 / (n_boot - 1))
+    assert big.sum() > 0 and (np.abs(ratio - 1) < tol + 0.05).all(), (ratio.min(), ratio.max(), tol)
+    # pooled: the mean of the ratios is far tighter than any single one
+    assert abs(ratio.mean() - 1) < 6 * np.sqrt(2.0 / (n_boot - 1) / big.sum()) + 0.01
+    cells = n * p >= 5                                 # chi-square approximation holds cell by cell
+    dof = int(cells.sum()) - (1 if cells.all() else 0)
+    pearson = (((counts[:, cells] - n * p[cells]) ** 2) / (n * p[cells])).sum(axis=1)
+    if dof > 30:
+        assert (np.abs(pearson - dof) < 6 * np.sqrt(2.0 * dof)).all(), (pearson.min(), pearson.max(), dof)
+        assert abs(pearson.mean() - dof) < 6 * np.sqrt(2.0 * dof / n_boot) + 0.002 * dof
+    # negative covariance between classes (-n p_i p_j): the two largest classes
+    i, j = np.argsort(p)[-2:]
+    cov = np.cov(counts[:, i], counts[:, j])[0, 1]
+    sd = np.sqrt(n * p[i] * (1 - p[i]) * n * p[j] * (1 - p[j]) / n_boot)
+    assert abs(cov + n * p[i] * p[j]) < 6 * sd * np.sqrt(2)
+
+
 def test_bootstrap_draw_and_em(oracle, native_libs):
     """The multinomial draw is only distributional (the reference draws from
     numpy's unseeded generator): totals exact, mean n*p within 6 sigma; the EM
@@ -378,7 +445,7 @@ def test_bootstrap_draw_and_em(oracle, native_libs):
     quant = infer._QuantHandle.from_csr(n_tx, offsets, targets, class_count)
     x0 = 1.0 / l
     x0 /= x0.sum()
-    n_boot = 40
+    n_boot = 100
     out, counts, iters = quant.bootstrap(n_boot, 1234, x0, l, want_counts=True)
     out2, counts2, _ = quant.bootstrap(n_boot, 1234, x0, l, want_counts=True)
     quant.close()
@@ -391,10 +458,58 @@ def test_bootstrap_draw_and_em(oracle, native_libs):
     sigma = np.sqrt(n * p * (1 - p) / n_boot)
     assert (np.abs(mean - n * p) < 6 * sigma + 1).all()
     assert len({c.tobytes() for c in counts}) == n_boot   # replicates differ
+    _check_multinomial_dispersion(counts, class_count)
     for b in (0, n_boot - 1):
         x_ref, it_ref = oracle.em(x0, l, class_map, counts[b].astype('f8'))
         assert it_ref == iters[b]
         np.testing.assert_allclose(out[b], x_ref, rtol=1e-8, atol=1e-300)
+
+
+def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs):
+    """BASELINE.json configs[4] in shape (paired 2x100 reads mapped on the GPU, then `-b 100`,
+    seekmer/infer.py:79-82, 108-111) at a size the oracle EM still handles: 1.2 M pairs are
+    mapped, the class table stays in HBM, skm_quant_bootstrap draws 100 resamples from it.
+    Totals are exact, first and second moments follow multinomial(n, count / n), and the EM on
+    the drawn counts equals the oracle's EM on the same counts (iteration count equal, x within
+    1e-8) for three replicates; the main estimate is the x0 of every replicate (:118)."""
+    from seekmer_amd import synth, index_builder, mapper, common, infer
+    ids, pool, tx_offsets = synth.transcriptome(4, 300)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    n_units = 1_200_000
+    bases, offsets = synth.reads(4, pool, tx_offsets, 0, n_units, 100, True)
+    result = mapper.MapResult(index)
+    mapper.ReadMapper(index, result).map_batch(common.ReadBatch(n_units, bases, offsets, True))
+    summarized = result.summarize()
+    n_tx = len(ids)
+    assert summarized.class_count.size > 1000 and summarized.aligned > 0.9 * n_units
+    main = infer.quantify(summarized)
+    eff = summarized.effective_lengths.astype('f8')
+    x0 = main.copy()
+    x0 /= x0.sum()
+    quant = infer._QuantHandle.from_map_result(result, n_tx)
+    n_boot = 100
+    out, counts, iters = quant.bootstrap(n_boot, 20240, x0, eff, want_counts=True)
+    # the handle holds the observed counts again afterwards
+    x_main, it_main = quant.em(1.0 / eff / (1.0 / eff).sum(), eff)
+    quant.close()
+    class_count = summarized.class_count
+    assert (counts.sum(axis=1) == class_count.sum()).all()
+    mean = counts.mean(axis=0)
+    n = class_count.sum()
+    p = class_count / n
+    assert (np.abs(mean - n * p) < 6 * np.sqrt(n * p * (1 - p) / n_boot) + 1).all()
+    _check_multinomial_dispersion(counts, class_count)
+    for b in (0, 41, n_boot - 1):
+        x_ref, it_ref = oracle.em(x0, eff, summarized.class_map, counts[b].astype('f8'))
+        assert it_ref == iters[b]
+        np.testing.assert_allclose(out[b], x_ref, rtol=1e-8, atol=1e-300)
+    x_ref, it_ref = oracle.em(1.0 / eff / (1.0 / eff).sum(), eff, summarized.class_map, class_count)
+    assert it_ref == it_main
+    np.testing.assert_allclose(x_main, x_ref, rtol=1e-8, atol=1e-300)
+    # and through the module surface: bootstrap_quantify returns TPM vectors (sum 1e6)
+    tpms = infer.bootstrap_quantify(summarized, main, 3, seed=20240)
+    assert len(tpms) == 3 and all(abs(t.sum() - 1e6) < 1e-3 for t in tpms)
+    np.testing.assert_allclose(tpms[0], infer._tpm(out[0].copy()), rtol=1e-12, atol=0)
 
 
 def test_cli_end_to_end(oracle, native_libs, chr21, chr21_oracle_index, pairs21, tmp_path):
@@ -486,6 +601,25 @@ def test_full_size_properties(oracle, native_libs):
     assert single.fragment_length_counts.sum() == 2 * n_units  # every read counted
 
 
+def _reference_cell_weights(transcripts, base_matrix, seed):
+    """seekmer/impute.py:187-226 spelled out with numpy / sklearn only (nothing from
+    seekmer_amd): i8 gene sums per cell, Pearson correlation, the off-diagonal correlations cut
+    in two by 1-D 2-means, the upper cluster keeps its value."""
+    import sklearn.cluster
+    genes, transcript_gene_map = np.unique(transcripts['gene_id'], return_inverse=True)
+    gene_matrix = np.zeros((len(base_matrix), len(genes)), dtype='i8')
+    for i in range(len(genes)):
+        gene_matrix[:, i] = base_matrix[:, transcript_gene_map == i].sum(axis=1)
+    gene_matrix = gene_matrix[:, genes != b'']
+    weights = np.corrcoef(gene_matrix)
+    flattened = weights[(weights == weights) & (weights != 1.0)]
+    kmean = sklearn.cluster.KMeans(2, random_state=seed)
+    kmean.fit(flattened[:, None])
+    weights[weights != weights] = 0.0
+    keep = kmean.predict(weights.flatten()[:, None]) == kmean.cluster_centers_.argmax()
+    return np.where(keep.reshape(weights.shape), weights, 0.0)
+
+
 def test_impute_end_to_end(oracle, native_libs, tmp_path):
     """`seekmer impute` (seekmer/impute.py:54-125) on five small cells of two expression
     profiles: FASTQ files -> tpm.csv through the CLI, against the same pipeline spelled out on
@@ -493,7 +627,7 @@ def test_impute_end_to_end(oracle, native_libs, tmp_path):
     counts, second-round EM).  The reference's own impute module cannot be run here (it imports
     logbook): parity of this stage is unpinned beyond the restated arithmetic."""
     import pandas
-    from seekmer_amd import synth, index_builder, common, impute
+    from seekmer_amd import synth, index_builder, common
     from seekmer_amd.__main__ import main
     ids, pool, tx_offsets = synth.transcriptome(5, 30)
     index = index_builder.build_pooled(ids, pool, tx_offsets)
@@ -535,7 +669,7 @@ def test_impute_end_to_end(oracle, native_libs, tmp_path):
         fld_total += fld
     eff = oracle.effective_lengths(fld_total, oindex.lengths)
     base = np.asarray([oracle.quantify(eff, class_map, class_count)[0] for class_map, class_count in tables])
-    weight = impute.cell_weights(index, base, seed=0) ** 4
+    weight = _reference_cell_weights(index.transcripts, base, seed=0) ** 4
     np.testing.assert_allclose(pandas.read_csv(out / 'weight.csv', index_col=0).to_numpy() ** 4, weight,
                                rtol=1e-9, atol=0)
     shifted, start = [], 0

@@ -55,6 +55,69 @@ def test_builder_edge_inputs(native_libs, oracle):
     _same_index(index, oracle.build_index(seqs))
 
 
+def test_builder_never_leaves_an_occupied_slot_unassigned(native_libs, oracle):
+    """SURVEY.md (finding 3 / row a9) records, for the reference's 3-transcript FASTA, one
+    occupied k-mer slot whose position was never assigned and a 24-base contig without
+    targets.  Neither can come out of _assemble_contigs (_index_builder.pyx:428-487): links are
+    only ever made between two consecutive NEW k-mers (:283-288), so the graph is a set of
+    disjoint simple paths, every path has an end that starts a walk (:436-445), a walk covers its
+    whole path (:458-471), and a contig of n k-mers is 25*ceil(n/25) + (n-1)%25 = n + 24 >= 25
+    bases long (:466-476).  DESIGN.md section 2 spells the argument out; here it is checked on
+    the graph shapes that could break it -- tandem repeats (would-be cycles), hairpins, even
+    palindromes (a k-mer followed by its own reverse complement), shared pieces in both
+    orientations, low-complexity sequence -- and on the reference's own 3-transcript file."""
+    from seekmer_amd import index_builder
+    rng = np.random.default_rng(0)
+    comp = bytes.maketrans(b'ACGT', b'TGCA')
+
+    def rnd(n):
+        return bytes(rng.choice(list(b'ACGT'), n).astype(np.uint8))
+
+    def check(seqs, compare_product):
+        ix = oracle.build_index(seqs)
+        occupied = ix.kmers['kmer'] != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert (ix.kmers['offset'][occupied] >= 0).all()
+        assert (ix.kmers['offset'][~occupied] < 0).all()          # empty slots are (0, -1)
+        if ix.contigs.size:
+            assert ix.contigs['length'].min() >= 25
+            assert (ix.contigs['target_count'] > 0).all()
+            # every occupied slot lies on a contig: the lengths add up
+            assert occupied.sum() == (ix.contigs['length'] - 24).sum()
+        if compare_product:
+            index = index_builder.build([b'T%d' % i for i in range(len(seqs))], seqs)
+            _same_index(index, ix)
+
+    _, seqs3 = oracle.read_fasta(os.path.join(GOLDEN, 'human.cdna.21.with_extra.fa.gz'))
+    check(seqs3, True)
+    for trial in range(240):
+        kind = trial % 6
+        core = rnd(int(rng.integers(30, 200)))
+        if kind == 0:
+            unit = rnd(int(rng.integers(1, 40)))
+            seqs = [unit * int(rng.integers(2, 10)) + rnd(int(rng.integers(0, 30)))]
+        elif kind == 1:
+            seqs = [core + core.translate(comp)[::-1]]
+        elif kind == 2:
+            seqs = []
+            for _ in range(int(rng.integers(2, 6))):
+                a = int(rng.integers(0, len(core) - 26))
+                b = int(rng.integers(a + 25, len(core) + 1))
+                piece = core[a:b]
+                if rng.random() < 0.5:
+                    piece = piece.translate(comp)[::-1]
+                seqs.append(rnd(int(rng.integers(0, 40))) + piece + rnd(int(rng.integers(0, 40))))
+        elif kind == 3:
+            half = rnd(12)
+            palindrome = half + half.translate(comp)[::-1]
+            seqs = [rnd(30) + palindrome + rnd(30), rnd(10) + palindrome + rnd(10), palindrome * 3]
+        elif kind == 4:
+            seqs = [bytes(rng.choice(list(b'AC'), int(rng.integers(25, 120))).astype(np.uint8))
+                    for _ in range(4)]
+        else:
+            seqs = [core + rnd(5) + core[10:] + core.translate(comp)[::-1][5:], core[::-1]]
+        check(seqs, trial < 60)
+
+
 def test_build_rejects_empty(native_libs):
     from seekmer_amd import index_builder
     with pytest.raises(ValueError):
