@@ -80,6 +80,14 @@ int skm_index_destroy(skm_index *index);
  * ends from the contig row instead of the pool) [7]=1 when every contig's target
  * slice ascends by signed entry (short list merges then run on registers) */
 int skm_index_info(const skm_index *index, int64_t info[8]);
+/* How the device copy of the k-mer table is probed.  The reference's table is a set
+ * (KMerIndex.map_kmer, seekmer/_common.pyx:54-97, returns the position stored with a k-mer
+ * or none); the device keeps the same set a second time in 64-byte buckets of four entries
+ * under a cheap hash, one sector per lookup.  layout[0]=1 when that copy is in use, 0 when
+ * the reference's own layout is probed (a table the reference's probe does not reach
+ * everywhere, or one holding a k-mer twice); [1]=buckets [2]=k-mers placed [3]=placed outside
+ * their home bucket [4]=k-mers met twice [5]=slots the reference's probe does not reach. */
+int skm_index_layout(const skm_index *index, int64_t layout[8]);
 
 /* ------------------------------------------------------------------ mapper
  * One handle = ReadMapper + the MapResult it feeds
@@ -105,11 +113,15 @@ int skm_mapper_map_batch_device(skm_mapper *mapper, const void *d_bases,
 /* Per-unit results of the LAST batch (what ReadMapper keeps in `results` and
  * `span`, seekmer/_mapper.pyx:83-99): any pointer may be NULL.  counts[u] =
  * number of targets, entries = signed target entries of all units back to
- * back in unit order (cap_entries bounds it; *n_entries = needed size). */
+ * back in unit order (cap_entries bounds it; *n_entries = needed size).
+ * begin / end / anchor are the MappedSpan fields (seekmer/_common.pxd:31-35);
+ * nothing on the infer path reads them, so they are only written for batches
+ * mapped after skm_mapper_keep_spans(mapper, 1) (SKM_ERR_STATE otherwise). */
 int skm_mapper_last_batch(skm_mapper *mapper, int32_t *begin, int32_t *end,
                           int32_t *anchor_entry, int32_t *anchor_offset,
                           int32_t *counts, int32_t *entries,
                           int64_t cap_entries, int64_t *n_entries);
+int skm_mapper_keep_spans(skm_mapper *mapper, int enable);
 /* Counter sizes (MapResult.summarize, seekmer/mapper.py:77-104):
  * summary[0]=C classes [1]=M (class,target) rows [2]=unaligned [3]=total units */
 int skm_mapper_summary(skm_mapper *mapper, int64_t summary[4]);

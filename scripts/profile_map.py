@@ -48,7 +48,7 @@ def main():
     _native.check(hip.skm_device_malloc(0, offsets.size * 8, ctypes.byref(d_off)))
     _native.check(hip.skm_device_upload(0, d_bases, bases.ctypes.data, bases.size))
     _native.check(hip.skm_device_upload(0, d_off, offsets.ctypes.data, offsets.size * 8))
-    result = mapper.MapResult(index)
+    result = mapper.MapResult(index, keep_spans=args.sorted)
     if args.stats:
         result.set_stats(True)
     for rep in range(args.reps):

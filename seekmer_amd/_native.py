@@ -43,6 +43,7 @@ HIP_SYMBOLS = {
                                         ctypes.c_int, c_void_pp]),
     'skm_index_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_index_info': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
+    'skm_index_layout': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_mapper_create': (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
     'skm_mapper_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_map_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64p, c_i64,
@@ -52,6 +53,7 @@ HIP_SYMBOLS = {
                                                    ctypes.c_int32]),
     'skm_mapper_last_batch': (ctypes.c_int, [ctypes.c_void_p, c_i32p, c_i32p, c_i32p, c_i32p,
                                              c_i32p, c_i32p, c_i64, c_i64p]),
+    'skm_mapper_keep_spans': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'skm_mapper_summary': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_mapper_export': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_i32p, c_i64p, c_i64p, c_i64p]),
     'skm_mapper_merge': (ctypes.c_int, [ctypes.c_void_p, c_i64, c_i64p, c_i32p, c_i64p, c_i64p,

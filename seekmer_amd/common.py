@@ -77,7 +77,12 @@ class KMerIndex:
         _native.check(_native.hip().skm_index_info(self.device_handle(device), info))
         names = ('n_slots', 'n_contigs', 'n_bases', 'n_targets', 'max_target_count', 'device_bytes',
                  'edge_windows', 'sorted_targets')
-        return dict(zip(names, info))
+        out = dict(zip(names, info))
+        layout = (ctypes.c_int64 * 8)()
+        _native.check(_native.hip().skm_index_layout(self.device_handle(device), layout))
+        out.update(zip(('bucketed', 'buckets', 'bucket_kmers', 'bucket_overflowed', 'kmers_twice',
+                        'slots_unreached'), layout))
+        return out
 
     def release(self):
         with self._lock:

@@ -101,8 +101,9 @@ int set_device(int device)
 struct skm_index {
     int device = 0;
     DevIndex d{};
-    void *kmers = nullptr, *contigs = nullptr, *seq2 = nullptr, *targets = nullptr;
+    void *kmers = nullptr, *contigs = nullptr, *seq2 = nullptr, *targets = nullptr, *buckets = nullptr;
     int64_t n_slots = 0, bytes = 0;
+    int64_t layout[8] = {0};          // skm_index_layout
     int cu_count = 256;
 };
 
@@ -124,13 +125,15 @@ struct skm_mapper {
     DBuf<uint32_t> records;
     DBuf<int32_t> workspace;
     DBuf<char> mate1;
-    DBuf<int32_t> unit_begin, unit_end, unit_count;
+    DBuf<int32_t> unit_begin, unit_end, rec_unit;
     DBuf<Coord> unit_anchor;
-    DBuf<int64_t> unit_offset, unit_slot;
+    DBuf<int64_t> unit_slot;
+    DBuf<unsigned long long> rec_tuple;
     DBuf<unsigned long long> unit_claim, claim_scan;
     DBuf<char> scan_temp;
     unsigned long long *pinned = nullptr;   // host-pinned readback words
-    DBuf<uint64_t> unit_key;
+    DBuf<uint64_t> rec_key;
+    bool keep_spans = false, last_spans = false;   // spans wanted / written by the last batch
     DBuf<int32_t> unit_entries;
     DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
     int grid_blocks = 0;
@@ -377,7 +380,6 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     d_ascii = nullptr;
     HIP_TRY(hipFree(d_contigs48));
     d_contigs48 = nullptr;
-    undo.dismiss();
     ix->n_slots = n_slots;
     ix->d.kmers = (const IndexEntry *)ix->kmers;
     ix->d.slot_mask = (uint32_t)(n_slots - 1);
@@ -392,6 +394,42 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     ix->d.sorted_targets = sorted_targets ? 1 : 0;
     ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(DevContig)
                 + n_targets * (int64_t)sizeof(int32_t) + n_words * 8;
+    {   // the same set of k-mers by bucket (skm_device.h: DevBucket): about one k-mer per bucket
+        const int64_t occupied = n_slots - empty;
+        uint64_t n_buckets = 16;
+        while ((int64_t)n_buckets < occupied) n_buckets <<= 1;
+        int log2_buckets = 0;
+        while ((1ULL << log2_buckets) < n_buckets) ++log2_buckets;
+        unsigned long long *d_report = nullptr;
+        unsigned long long report[4] = {0, 0, 0, 0};
+        const char *off = getenv("SKM_NO_BUCKETS");          // tuning aid: probe the reference's layout
+        if (!(off && off[0] == '1') && n_buckets <= (1ULL << 31)) {
+            auto undo_report = on_exit([&]() { (void)hipFree(d_report); });
+            HIP_TRY(hipMalloc(&ix->buckets, (size_t)n_buckets * sizeof(DevBucket)));
+            HIP_TRY(hipMalloc((void **)&d_report, sizeof(report)));
+            HIP_TRY(hipMemset(d_report, 0, sizeof(report)));
+            launch_bucket_build(ix->d, (uint64_t)n_slots, (DevBucket *)ix->buckets, (uint32_t)(n_buckets - 1),
+                                (uint32_t)(32 - log2_buckets), d_report, nullptr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(report, d_report, sizeof(report), hipMemcpyDeviceToHost));
+            ix->layout[1] = (int64_t)n_buckets;
+            ix->layout[2] = (int64_t)report[0];
+            ix->layout[3] = (int64_t)report[1];
+            ix->layout[4] = (int64_t)report[2];
+            ix->layout[5] = (int64_t)report[3];
+            if ((int64_t)report[0] == occupied && report[2] == 0 && report[3] == 0) {
+                ix->d.buckets = (const DevBucket *)ix->buckets;
+                ix->d.bucket_mask = (uint32_t)(n_buckets - 1);
+                ix->d.bucket_shift = (uint32_t)(32 - log2_buckets);
+                ix->bytes += (int64_t)n_buckets * (int64_t)sizeof(DevBucket);
+                ix->layout[0] = 1;
+            } else {                 // not a set the reference's probe reaches everywhere: its layout decides
+                HIP_TRY(hipFree(ix->buckets));
+                ix->buckets = nullptr;
+            }
+        }
+    }
+    undo.dismiss();
     *out = ix;
     return SKM_OK;
 }
@@ -401,6 +439,7 @@ extern "C" int skm_index_destroy(skm_index *ix)
     if (!ix) return SKM_OK;
     (void)hipSetDevice(ix->device);
     (void)hipFree(ix->kmers); (void)hipFree(ix->contigs); (void)hipFree(ix->targets); (void)hipFree(ix->seq2);
+    (void)hipFree(ix->buckets);
     delete ix;
     return SKM_OK;
 }
@@ -416,6 +455,13 @@ extern "C" int skm_index_info(const skm_index *ix, int64_t info[8])
     info[5] = ix->bytes;
     info[6] = ix->d.edge_windows;
     info[7] = ix->d.sorted_targets;
+    return SKM_OK;
+}
+
+extern "C" int skm_index_layout(const skm_index *ix, int64_t layout[8])
+{
+    if (!ix || !layout) return fail(SKM_ERR_ARG, "NULL argument");
+    for (int i = 0; i < 8; ++i) layout[i] = ix->layout[i];
     return SKM_OK;
 }
 
@@ -536,15 +582,19 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
 
     const int record_words = ((3 * words + 1 + 15) / 16) * 16;      // 64-byte records
     SKM_TRY(m->records.ensure((size_t)n_reads * record_words + 16));
-    SKM_TRY(m->unit_begin.ensure(n_units));
-    SKM_TRY(m->unit_end.ensure(n_units));
-    SKM_TRY(m->unit_count.ensure(n_units));
-    SKM_TRY(m->unit_anchor.ensure(n_units));
-    SKM_TRY(m->unit_offset.ensure(n_units));
+    if (n_units >= (1LL << 31)) return fail(SKM_ERR_ARG, "more than 2^31 - 1 units in one batch");
+    if (m->keep_spans) {
+        SKM_TRY(m->unit_begin.ensure(n_units));
+        SKM_TRY(m->unit_end.ensure(n_units));
+        SKM_TRY(m->unit_anchor.ensure(n_units));
+    }
+    m->last_spans = m->keep_spans;
+    SKM_TRY(m->rec_unit.ensure(n_units));
+    SKM_TRY(m->rec_tuple.ensure(n_units));
     SKM_TRY(m->unit_slot.ensure(n_units));
     SKM_TRY(m->unit_claim.ensure(n_units));
     SKM_TRY(m->claim_scan.ensure(n_units));
-    SKM_TRY(m->unit_key.ensure(n_units));
+    SKM_TRY(m->rec_key.ensure(n_units));
 
     SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
 
@@ -578,9 +628,10 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     b.unit_begin = m->unit_begin.p;
     b.unit_end = m->unit_end.p;
     b.unit_anchor = m->unit_anchor.p;
-    b.unit_count = m->unit_count.p;
-    b.unit_offset = m->unit_offset.p;
-    b.unit_key = m->unit_key.p;
+    b.keep_spans = m->keep_spans ? 1 : 0;
+    b.rec_unit = m->rec_unit.p;
+    b.rec_tuple = m->rec_tuple.p;
+    b.rec_key = m->rec_key.p;
     b.ids_cursor = m->batch_ctl.p + BC_IDS;
     b.fld = m->batch_ctl.p + BC_FLD;
     b.stats = m->batch_ctl.p + BC_STATS;
@@ -694,8 +745,8 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->counters.release();
     m->error.release(); m->bases.release(); m->offsets.release(); m->records.release();
     m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();
-    m->unit_count.release(); m->unit_anchor.release(); m->unit_offset.release();
-    m->unit_slot.release(); m->unit_key.release(); m->unit_entries.release(); m->batch_ctl.release();
+    m->rec_unit.release(); m->unit_anchor.release(); m->rec_tuple.release();
+    m->unit_slot.release(); m->rec_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
     if (m->pinned) (void)hipHostFree(m->pinned);
     m->unit_claim.release(); m->claim_scan.release(); m->scan_temp.release();
@@ -757,6 +808,8 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
     const int64_t n = m->last_units;
     if (n_entries) *n_entries = 0;
     if (n == 0) return SKM_OK;
+    if ((begin || end || anchor_entry || anchor_offset) && !m->last_spans)
+        return fail(SKM_ERR_STATE, "the spans of the last batch were not kept: call skm_mapper_keep_spans(mapper, 1) before mapping");
     if (begin) HIP_TRY(hipMemcpy(begin, m->unit_begin.p, n * 4, hipMemcpyDeviceToHost));
     if (end) HIP_TRY(hipMemcpy(end, m->unit_end.p, n * 4, hipMemcpyDeviceToHost));
     if (anchor_entry || anchor_offset) {
@@ -767,8 +820,22 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
             if (anchor_offset) anchor_offset[i] = a[i].offset;
         }
     }
-    std::vector<int32_t> cnt(n);
-    HIP_TRY(hipMemcpy(cnt.data(), m->unit_count.p, n * 4, hipMemcpyDeviceToHost));
+    if (!counts && !entries && !n_entries) return SKM_OK;
+    // the records of the batch (emission order) -> per unit
+    std::vector<int32_t> unit(n);
+    std::vector<unsigned long long> tuple(n);
+    HIP_TRY(hipMemcpy(unit.data(), m->rec_unit.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tuple.data(), m->rec_tuple.p, n * 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> cnt(n, 0);
+    std::vector<int64_t> off(n, 0);
+    std::vector<char> seen(n, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t u = unit[r];
+        if (u < 0 || u >= n || seen[u]) return fail(SKM_ERR_STATE, "record %lld names unit %lld", (long long)r, (long long)u);
+        seen[u] = 1;
+        cnt[u] = (int32_t)(tuple[r] >> 40);
+        off[u] = (int64_t)(tuple[r] & ((1ULL << 40) - 1));
+    }
     if (counts) memcpy(counts, cnt.data(), n * 4);
     if (n_entries) {
         int64_t total = 0;
@@ -776,9 +843,7 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
         *n_entries = total;           // the arena itself has per-wave slack
     }
     if (entries) {
-        std::vector<int64_t> off(n);
         std::vector<int32_t> raw((size_t)std::max<int64_t>(m->last_ids, 1));
-        HIP_TRY(hipMemcpy(off.data(), m->unit_offset.p, n * 8, hipMemcpyDeviceToHost));
         if (m->last_ids)
             HIP_TRY(hipMemcpy(raw.data(), m->unit_entries.p, (size_t)m->last_ids * 4, hipMemcpyDeviceToHost));
         int64_t pos = 0;
@@ -788,6 +853,14 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
             pos += cnt[u];
         }
     }
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_keep_spans(skm_mapper *m, int enable)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    std::lock_guard<std::mutex> lock(m->mu);
+    m->keep_spans = enable != 0;
     return SKM_OK;
 }
 

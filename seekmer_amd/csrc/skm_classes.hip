@@ -75,6 +75,7 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     __shared__ unsigned int s_unaligned;
     if (threadIdx.x == 0) s_unaligned = 0;
     __syncthreads();
+    // (u walks the batch's RECORDS, skm_kernels.h: MapBatch; unit_slot / unit_claim are by record)
     for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
          u += (int64_t)gridDim.x * blockDim.x) {
         // every unit leaves with ONE store to unit_slot (new units) and ONE to unit_claim, issued
@@ -85,7 +86,7 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
         if (retry_deferred && unit_slot[u] != -2) {
             touched = false;                  // counted in an earlier pass: only its claim is cleared
         } else {
-            const unsigned long long key = b.unit_key[u];
+            const unsigned long long key = b.rec_key[u];
             if (key == 0) {                   // empty tuple = unaligned, mapper.py:87
                 const unsigned long long peers = __ballot(1);
                 if ((int)(threadIdx.x & 63) == __builtin_ctzll(peers))
@@ -100,10 +101,10 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
                 } else {
                     // the creator of a class stores its tuple later (class_commit_kernel): one
                     // class (bits 40+) and n arena ids (bits 0-39), placed by a device-wide scan
-                    if (claimed) claim = (1ULL << 40) | (unsigned long long)b.unit_count[u];
+                    if (claimed) claim = (1ULL << 40) | (b.rec_tuple[u] >> 40);
                     atomicAdd(&t.slots[slot].count, 1ULL);
-                    if (claimed || seen > (unsigned long long)(unit_base + u))
-                        atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + u));
+                    const unsigned long long unit = (unsigned long long)(unit_base + b.rec_unit[u]);
+                    if (claimed || seen > unit) atomicMin(&t.slots[slot].first_seen, unit);
                     where = (int64_t)slot;
                 }
             }
@@ -136,7 +137,7 @@ class_commit_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot,
             continue;
         }
         const int64_t slot = unit_slot[u];
-        const int32_t *entries = b.unit_entries + b.unit_offset[u];
+        const int32_t *entries = b.unit_entries + (b.rec_tuple[u] & ((1ULL << 40) - 1));
         for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(entries[i]);
         t.slots[slot].tuple = tuple_pack(off, n);
         t.class_list[k] = slot;
@@ -167,11 +168,12 @@ class_verify_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot)
          u += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = unit_slot[u];
         if (slot < 0) continue;
-        const int n = b.unit_count[u];
+        const unsigned long long mine_at = b.rec_tuple[u];
+        const int n = (int)(mine_at >> 40);
         const long long stored = t.slots[slot].tuple;
         bool same = stored >= 0 && tuple_len(stored) == n;
         if (same) {
-            const int32_t *mine = b.unit_entries + b.unit_offset[u];
+            const int32_t *mine = b.unit_entries + (mine_at & ((1ULL << 40) - 1));
             const int32_t *ref = t.arena + tuple_offset(stored);
             for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
         }

@@ -14,12 +14,19 @@ struct MapBatch {
     int32_t paired;
     int32_t *workspace;           // per-context mask extension words (slices > 64 targets)
     void *mate1;                  // per-context parking slot of the mate-1 span and set (48 B)
-    // per-unit results
+    // Results.  Units finish out of order, so a wave writes what it finishes as RECORDS: 64
+    // finished units take 64 consecutive places of their block's own range (block b owns
+    // records [b * per_block, ...) like it owns those units), and the three stores of a wave
+    // are full sectors.  Record r = {unit index, class key, arena offset | tuple length << 40}.
+    int32_t *rec_unit;
+    uint64_t *rec_key;            // 64-bit class key, 0 = empty tuple
+    unsigned long long *rec_tuple;
+    // per-unit spans (begin, end, anchor of MappedSpan, _common.pxd:31-35), by unit index;
+    // only written when keep_spans is set (parity tests, diagnostics): nothing on the infer
+    // path reads them
+    int32_t keep_spans;
     int32_t *unit_begin, *unit_end;
     Coord *unit_anchor;
-    int32_t *unit_count;
-    int64_t *unit_offset;         // into unit_entries
-    uint64_t *unit_key;           // 64-bit class key, 0 = empty tuple
     int32_t *unit_entries;        // signed target entries, units in arena order
     int64_t ids_capacity;
     unsigned long long *ids_cursor;
@@ -42,6 +49,11 @@ constexpr int MAP_BLOCKS_PER_CU = 4;
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
 void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream);
+// build the bucket table from the reference table and check the reference probe (see DevBucket);
+// report: [0] placed [1] placed outside the home bucket [2] k-mers met twice [3] slots the
+// reference probe does not reach
+void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *buckets, uint32_t bucket_mask,
+                         uint32_t bucket_shift, unsigned long long *report, hipStream_t stream);
 void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bool stats,
                       hipStream_t stream);
 void launch_pack_sequences(const char *bases, int64_t n_bases, uint64_t *seq2, int64_t n_words,
@@ -78,6 +90,8 @@ struct ClassTable {
     int *error;                   // SKM_ERR_* raised by a kernel
 };
 constexpr int CLASS_PROBE_LIMIT = 128;
+// (the class kernels walk the batch record by record; unit_slot / unit_claim / claim_scan are
+// indexed by record)
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
                          int64_t *unit_slot, unsigned long long *unit_claim, bool retry_deferred,
                          hipStream_t stream);

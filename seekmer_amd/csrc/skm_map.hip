@@ -7,8 +7,9 @@
 // by a coalesced streaming kernel to 2 bits per base + an "is upper-case
 // ACGT" bit plane, k-mers and 8-base windows are then funnel-shifted out of
 // registers instead of being re-encoded byte by byte, contig bases are
-// fetched from a 2-bit pool, and the running target list of a lane lives in a
-// small per-lane slice of an HBM workspace.
+// fetched from a 2-bit pool, the k-mer table is probed through a bucketised
+// device copy (skm_device.h: DevBucket), and the running target list of a unit
+// is never materialised: it is a slice of the index plus a keep-mask.
 #include "skm_device.h"
 #include "skm_kernels.h"
 
@@ -136,6 +137,81 @@ pack_contigs_kernel(const ContigEntry *__restrict__ in, int64_t n, DevContig *__
     }
 }
 
+// ------------------------------------------------- bucket table construction
+__global__ void __launch_bounds__(256)
+bucket_init_kernel(DevBucket *buckets, uint64_t n_buckets)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_buckets * 4;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        buckets[i >> 2].kmer[i & 3] = KMER_INVALID;
+        buckets[i >> 2].pos[i & 3] = Coord{0, -1};
+    }
+}
+
+// every occupied slot of the reference table goes into the first free entry from its bucket
+// on; report[0] = entries placed, [1] = placed outside their home bucket, [2] = k-mers met
+// twice (the table is not a set: the caller drops the bucket table)
+__global__ void __launch_bounds__(256)
+bucket_fill_kernel(const IndexEntry *__restrict__ kmers, uint64_t n_slots, DevBucket *buckets,
+                   uint32_t bucket_mask, uint32_t bucket_shift, unsigned long long *report)
+{
+    unsigned long long placed = 0, moved = 0, twice = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_slots;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const IndexEntry e = kmers[i];
+        if (e.kmer == KMER_INVALID) continue;
+        const uint64_t rc = kmer_revcomp(e.kmer);
+        const uint32_t home = bucket_hash(e.kmer < rc ? e.kmer : rc) >> bucket_shift;
+        uint32_t b = home;
+        bool done = false;
+        for (uint32_t n = 0; n <= bucket_mask && !done; ++n) {
+            for (int j = 0; j < 4 && !done; ++j) {
+                const unsigned long long old = atomicCAS(
+                    reinterpret_cast<unsigned long long *>(&buckets[b].kmer[j]), KMER_INVALID, e.kmer);
+                if (old == KMER_INVALID) {
+                    buckets[b].pos[j] = e.pos;
+                    ++placed;
+                    if (b != home) ++moved;
+                    done = true;
+                } else if (old == e.kmer) {
+                    ++twice;
+                    done = true;
+                }
+            }
+            b = (b + 1) & bucket_mask;
+        }
+    }
+    if (placed) atomicAdd(&report[0], placed);
+    if (moved) atomicAdd(&report[1], moved);
+    if (twice) atomicAdd(&report[2], twice);
+}
+
+// The bucket table answers "is this k-mer in the set, and with which position"; the
+// reference's probe (_common.pyx:75-97) answers the same question exactly when it finds every
+// stored k-mer in the slot that stores it.  report[3] counts the slots where it does not
+// (an empty slot or an equal k-mer between the home slot and the slot).
+__global__ void __launch_bounds__(256)
+probe_check_kernel(DevIndex ix, uint64_t n_slots, unsigned long long *report)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_slots;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t kmer = ix.kmers[i].kmer;
+        if (kmer == KMER_INVALID) continue;
+        const uint64_t rc = kmer_revcomp(kmer);
+        uint32_t slot = kmer_hash(kmer < rc ? kmer : rc) & ix.slot_mask;
+        bool reached = false;
+        for (uint64_t n = 0; n <= ix.slot_mask; ++n) {
+            const uint64_t stored = ix.kmers[slot].kmer;
+            if (stored == KMER_INVALID) break;
+            if (stored == kmer || stored == rc) { reached = slot == (uint32_t)i; break; }
+            slot = (slot + 1) & ix.slot_mask;
+        }
+        if (!reached) ++bad;
+    }
+    if (bad) atomicAdd(&report[3], bad);
+}
+
 // ------------------------------------------------------------------- mapper
 // Running target list of a context.  KMerIndex.map_contig (_common.pyx:143-179)
 // copies the first contig's target slice (reversed and complemented for a
@@ -218,25 +294,41 @@ constexpr int LIST_REGS = 16;
 #else
 #define LIST_FAST(stats) (!(stats))
 #endif
-constexpr int32_t NO_ENTRY = INT32_MIN;      // (would be transcript 2^31-1: cannot occur, n_targets < 2^31)
+constexpr int32_t NO_ENTRY = INT32_MIN;      // (would be transcript 2^31-1: cannot occur, n_targets < 2^30)
+constexpr int32_t NO_ENTRY_B = INT32_MIN + 1; // the same for the other side of a comparison: never equal to NO_ENTRY
 
-// entries at list positions 0..15 of a slice of 1..16 targets; NO_ENTRY where
-// the position is outside the slice or cleared in `keep`
+// entries at list positions 0..15 of a slice of 1..16 targets; `absent` where the position is
+// outside the slice or cleared in `keep`.  `twice` = two neighbours of the (whole, ascending)
+// slice are equal: a transcript listed twice (two such classes in the reference's chr21 data).
 __device__ __forceinline__ void load_list(const DevIndex &ix, int32_t start, int32_t length, bool forward,
-                                          uint32_t keep, int32_t (&e)[LIST_REGS])
+                                          uint32_t keep, int32_t absent, int32_t (&e)[LIST_REGS], bool &twice)
 {
     const int last = length - 1;
+    int32_t v[LIST_REGS];
 #pragma unroll
     for (int i = 0; i < LIST_REGS; ++i) {
         const int p = min(i, last);
         const int32_t raw = target_at(ix, forward ? start + p : start + last - p);
-        e[i] = (i <= last && ((keep >> i) & 1u)) ? (forward ? raw : ~raw) : NO_ENTRY;
+        v[i] = forward ? raw : ~raw;
     }
+    bool same = false;
+#pragma unroll
+    for (int i = 1; i < LIST_REGS; ++i) same |= (i <= last) & (v[i] == v[i - 1]);
+    twice = same;
+#pragma unroll
+    for (int i = 0; i < LIST_REGS; ++i) e[i] = (i <= last && ((keep >> i) & 1u)) ? v[i] : absent;
+}
+__device__ __forceinline__ void load_list(const DevIndex &ix, int32_t start, int32_t length, bool forward,
+                                          uint32_t keep, int32_t (&e)[LIST_REGS])
+{
+    bool twice;
+    load_list(ix, start, length, forward, keep, NO_ENTRY, e, twice);
 }
 
 // positions of `a` (ascending, NO_ENTRY = absent) that a two-pointer walk against the
-// multiset `b` keeps: the r-th copy of a value survives iff b holds more than r copies
-__device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS])
+// multiset `b` (NO_ENTRY_B = absent) keeps: the r-th copy of a value survives iff b holds more
+// than r copies
+__device__ __forceinline__ uint32_t keep_common_exact(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS])
 {
     uint32_t keep = 0;
     int32_t prev = NO_ENTRY;
@@ -251,6 +343,23 @@ __device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], c
         run = (present && v == prev) ? run + 1 : (present ? 0 : run);
         if (present) prev = v;
         if (present && run < copies) keep |= 1u << i;
+    }
+    return keep;
+}
+// The same when no value occurs twice on either side (`twice` of load_list, all but a handful
+// of slices): a position survives iff its value occurs in b -- 256 compares accumulated as lane
+// masks on the scalar side, two instructions apiece and no carry chains.
+__device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS],
+                                                bool twice)
+{
+    if (twice) return keep_common_exact(a, b);
+    uint32_t keep = 0;
+#pragma unroll
+    for (int i = 0; i < LIST_REGS; ++i) {
+        bool present = false;
+#pragma unroll
+        for (int j = 0; j < LIST_REGS; ++j) present |= a[i] == b[j];
+        keep |= present ? (1u << i) : 0u;
     }
     return keep;
 }
@@ -271,9 +380,10 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
     if (LIST_FAST(STATS) && ix.sorted_targets && set.length <= LIST_REGS && length <= LIST_REGS) {
         if (length == 0) return false;
         int32_t a[LIST_REGS], t[LIST_REGS];
-        load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, a);
-        load_list(ix, start, length, forward, 0xffffu, t);     // (order within the slice is immaterial)
-        const uint32_t keep = keep_common(a, t);
+        bool twice_a, twice_t;
+        load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, NO_ENTRY, a, twice_a);
+        load_list(ix, start, length, forward, 0xffffu, NO_ENTRY_B, t, twice_t);   // (order within the slice is immaterial)
+        const uint32_t keep = keep_common(a, t, twice_a | twice_t);
         if (keep == 0) return false;
         set.word0 = keep;
         span.n = __builtin_popcount(keep);
@@ -412,12 +522,13 @@ __device__ __forceinline__ bool intersect(const DevIndex &ix, TSet &a, Span &s1,
     if (s2.n == 0) return false;
     if (LIST_FAST(STATS) && ix.sorted_targets && a.length <= LIST_REGS && b2.length <= LIST_REGS) {
         int32_t e1[LIST_REGS], e2[LIST_REGS];
-        load_list(ix, a.start, a.length, a.forward, (uint32_t)a.word0, e1);
+        bool twice1, twice2;
+        load_list(ix, a.start, a.length, a.forward, (uint32_t)a.word0, NO_ENTRY, e1, twice1);
         // mate 2 is compared complemented: ~entry(i).  load_list with the orientation flipped
         // yields exactly that at mirrored positions, and positions do not matter on this side.
         const uint32_t mirrored = __brev((uint32_t)b2.word0) >> (32 - b2.length);
-        load_list(ix, b2.start, b2.length, !b2.forward, mirrored, e2);
-        const uint32_t keep = keep_common(e1, e2);
+        load_list(ix, b2.start, b2.length, !b2.forward, mirrored, NO_ENTRY_B, e2, twice2);
+        const uint32_t keep = keep_common(e1, e2, twice1 | twice2);
         a.word0 = keep;
         if (keep == 0) return false;
         s1.n = __builtin_popcount(keep);
@@ -527,7 +638,17 @@ __device__ __forceinline__ int action_of(int state)
     return A_EMIT;                                    // ST_UNIT_DONE
 }
 
-template <bool STATS>
+// the one place the k-mer table is asked: bucket table (BUCKETS) or the reference's layout
+template <bool STATS, bool BUCKETS>
+__device__ __forceinline__ Coord lookup_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
+{
+    if (BUCKETS) return map_kmer_buckets(ix, kmer);
+    return map_kmer<STATS>(ix, kmer, st);
+}
+
+// STATS: the counting build (access counters, scheduler census; always the reference's table
+// layout).  BUCKETS: the index carries a bucket table (every built index does).
+template <bool STATS, bool BUCKETS>
 __global__ void __launch_bounds__(MAP_THREADS, SKM_MAP_WAVES_PER_EU)
 map_units_kernel(DevIndex ix, MapBatch b)
 {
@@ -672,7 +793,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 }
             } else if (valid && action == A_LOOKUP) {
                 // ---------------------------------- the one index lookup site
-                const Coord pos = map_kmer<STATS>(ix, kmer, &ls);
+                const Coord pos = lookup_kmer<STATS, BUCKETS>(ix, kmer, &ls);
                 span.anchor = pos;
                 if (state == Y_FIRST) {                       // _find_first_kmer, :199-216
                     if (pos.offset >= 0) {
@@ -700,10 +821,71 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     span.n = 0;
                     state = N_AFTER;
                 }
+            } else if (valid && action == A_SCAN && BUCKETS) {
+                // ------------- _find_first_kmer's roll, :207-216, over the bucket table: the next
+                // SCAN_ROUNDS k-mers of the read are looked up TOGETHER (their buckets are
+                // independent loads: one memory latency for the lot) and then judged in read
+                // order, so the first hit is the one the reference's one-by-one roll stops at.
+                // A k-mer joins the group while its last base is in the 16-base look-ahead.
+                uint64_t cand[SCAN_ROUNDS];
+                cand[0] = kmer;
+                int m = 1;
+#pragma unroll
+                for (int j = 1; j < SCAN_ROUNDS; ++j) {
+                    const int at = scan_i + j - 1;                 // the base that makes candidate j
+                    const bool ok = m == j && at < rv.len && (at >> 4) == (scan_i >> 4);
+                    cand[j] = ok ? ((cand[j - 1] << 2) | ((look >> (30 - 2 * (at & 15))) & 3u)) & KMER_MASK
+                                 : cand[j - 1];
+                    m += ok ? 1 : 0;
+                }
+                uint64_t rcs[SCAN_ROUNDS];
+                uint32_t home[SCAN_ROUNDS];
+                BucketKeys keys[SCAN_ROUNDS];
+#pragma unroll
+                for (int j = 0; j < SCAN_ROUNDS; ++j) {
+                    rcs[j] = kmer_revcomp(cand[j]);
+                    home[j] = bucket_hash(cand[j] < rcs[j] ? cand[j] : rcs[j]) >> ix.bucket_shift;
+                    keys[j] = bucket_keys(ix, home[j]);            // (j >= m repeats the last one: same sector)
+                }
+                int last = 0;                                      // candidate the roll stopped at
+                Coord pos = invalid_coord();
+#pragma unroll
+                for (int j = 0; j < SCAN_ROUNDS; ++j) {
+                    if (j < m && pos.offset < 0 && last == (j == 0 ? 0 : j - 1)) {
+                        last = j;
+                        kmer = cand[j];
+                        bool flip = false;
+                        const int e = bucket_find(keys[j], cand[j], rcs[j], flip);
+                        pos = invalid_coord();                     // (span.anchor is the LAST lookup's result)
+                        if (e >= 0) {
+                            const Coord c = bucket_at(ix, home[j])->pos[e];
+                            pos = flip ? Coord{~c.entry, c.offset} : c;
+                        } else if (e == -2) {                      // full bucket: the long way round
+                            pos = map_kmer_buckets(ix, cand[j]);
+                        }
+                        // (an occupied slot without a position, offset < 0, is a miss too: :203, :211)
+                    }
+                }
+                scan_i += last;
+                span.anchor = pos;
+                if (pos.offset >= 0) {
+                    span.begin = scan_i - K;
+                    span.end = span.begin;
+                    map_contig<STATS>(ix, pos, set, span, &ls);
+                    state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+                    anchored = true;
+                } else if (scan_i < rv.len) {
+                    if ((scan_i >> 4) != ((scan_i - last) >> 4)) look = read_half(rv, scan_i >> 4);
+                    kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
+                    ++scan_i;
+                    if ((scan_i & 15) == 0 && scan_i < rv.len) look = read_half(rv, scan_i >> 4);
+                } else {
+                    state = N_MATE_DONE;
+                }
             } else if (valid && action == A_SCAN) {
-                // ------------- _find_first_kmer's roll, :207-216, SCAN_ROUNDS k-mers per round
+                // ------------- the same roll over the reference's table layout, SCAN_ROUNDS k-mers per round
                 for (int round = 0; round < SCAN_ROUNDS && state == Y_SCAN; ++round) {
-                    const Coord pos = map_kmer<STATS>(ix, kmer, &ls);
+                    const Coord pos = lookup_kmer<STATS, BUCKETS>(ix, kmer, &ls);
                     span.anchor = pos;
                     if (pos.offset >= 0) {
                         span.begin = scan_i - K;
@@ -807,6 +989,12 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     if (STATS) { const unsigned long long t = clock64(); cyc[2 + N_ACTIONS + k] += t - t_e; t_e = t; }
                 };
                 int n_out = 0;
+                // (counted as done before its records are stored: a wave that sees the block
+                // finished leaves the loop, and the kernel's end orders the stores)
+                const unsigned long long finished = __ballot(valid);
+                uint32_t rec_base = 0;
+                if (lane == 0) rec_base = atomicAdd(&done_units, (uint32_t)__popcll(finished));
+                rec_base = __shfl(rec_base, 0, 64);
                 if (valid) {
                     if (b.paired) {
                         // map_read_pair, _mapper.pyx:129-144 (span/set = mate 2, parked = mate 1)
@@ -890,23 +1078,23 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     }
                     if (key == 0) key = 1;
                     phase(4);
-                    b.unit_offset[u] = off;
-                    b.unit_count[u] = n_out;
-                    b.unit_key[u] = n_out ? key : 0;
-                    b.unit_begin[u] = span.begin;
-                    b.unit_end[u] = span.end;
-                    b.unit_anchor[u] = span.anchor;
+                    // the wave's finished units take consecutive records of the block's range
+                    const int64_t r = block_first + rec_base + __popcll(finished & ((1ULL << lane) - 1));
+                    b.rec_unit[r] = (int32_t)u;
+                    b.rec_key[r] = n_out ? key : 0;
+                    b.rec_tuple[r] = (unsigned long long)off | ((unsigned long long)n_out << 40);
+                    if (b.keep_spans) {
+                        b.unit_begin[u] = span.begin;
+                        b.unit_end[u] = span.end;
+                        b.unit_anchor[u] = span.anchor;
+                    }
                     if (STATS) tuple_ids += n_out;
                 }
                 chunk_pos += wave_total;
                 phase(5);
                 // each of these contexts takes the block's next unit, or retires
-                const unsigned long long finished = __ballot(valid);
                 uint32_t base = 0;
-                if (lane == 0) {
-                    base = atomicAdd(&next_unit, (uint32_t)__popcll(finished));
-                    atomicAdd(&done_units, (uint32_t)__popcll(finished));
-                }
+                if (lane == 0) base = atomicAdd(&next_unit, (uint32_t)__popcll(finished));
                 base = __shfl(base, 0, 64);
                 if (valid) {
                     const uint32_t k = base + __popcll(finished & ((1ULL << lane) - 1));
@@ -1047,6 +1235,15 @@ void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs
                        (const ContigEntry *)contigs48, n_contigs, (DevContig *)contigs32);
 }
 
+void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *buckets, uint32_t bucket_mask,
+                         uint32_t bucket_shift, unsigned long long *report, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bucket_init_kernel, dim3(4096), dim3(256), 0, stream, buckets, (uint64_t)bucket_mask + 1);
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3(4096), dim3(256), 0, stream, ix.kmers, n_slots, buckets,
+                       bucket_mask, bucket_shift, report);
+    hipLaunchKernelGGL(probe_check_kernel, dim3(4096), dim3(256), 0, stream, ix, n_slots, report);
+}
+
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream)
 {
@@ -1063,9 +1260,11 @@ void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bo
 {
     if (b.n_units == 0) return;
     if (stats)
-        hipLaunchKernelGGL(map_units_kernel<true>, dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
+        hipLaunchKernelGGL((map_units_kernel<true, false>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
+    else if (ix.buckets)
+        hipLaunchKernelGGL((map_units_kernel<false, true>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
     else
-        hipLaunchKernelGGL(map_units_kernel<false>, dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
+        hipLaunchKernelGGL((map_units_kernel<false, false>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
 }
 
 }  // namespace skm

@@ -51,7 +51,9 @@ class SummarizedResult:
 class MapResult:
     """A mapping result collection with a lock (seekmer/mapper.py:40-145)."""
 
-    def __init__(self, index, readmap=None, device=0):
+    def __init__(self, index, readmap=None, device=0, keep_spans=False):
+        """keep_spans: also store every unit's MappedSpan (begin, end, anchor) for
+        ReadMapper.last_batch -- parity tests and diagnostics; inference does not read them."""
         self.lock = threading.Lock()
         self.index = index
         self.readmap = readmap
@@ -60,6 +62,9 @@ class MapResult:
         _native.check(_native.hip().skm_mapper_create(index.device_handle(device),
                                                       ctypes.byref(self._handle)))
         self._extra_fld = numpy.zeros(MAX_FRAGMENT_LENGTH, dtype='i8')
+        self.keep_spans = bool(keep_spans)
+        if keep_spans:
+            _native.check(_native.hip().skm_mapper_keep_spans(self._handle, 1))
 
     def __del__(self):
         handle = getattr(self, '_handle', None)
@@ -274,18 +279,29 @@ class ReadMapper:
             _native.ptr(batch.offsets, _native.c_i64p), batch.count, int(batch.paired)))
 
     def last_batch(self, n_units):
-        """(begin, end, anchor_entry, anchor_offset, counts, signed entries)"""
+        """(begin, end, anchor_entry, anchor_offset, counts, signed entries); the spans need a
+        MapResult created with keep_spans=True."""
+        spans = [numpy.zeros(max(n_units, 1), dtype=numpy.int32) for _ in range(4)]
         hip = _native.hip()
-        arrays = [numpy.zeros(max(n_units, 1), dtype=numpy.int32) for _ in range(5)]
+        _native.check(hip.skm_mapper_last_batch(
+            self.map_result._handle, *[_native.ptr(a, _native.c_i32p) for a in spans],
+            None, None, 0, None))
+        counts, entries = self.last_tuples(n_units)
+        return tuple(a[:n_units] for a in spans) + (counts, entries)
+
+    def last_tuples(self, n_units):
+        """(counts, signed entries) of the last batch, units in order."""
+        hip = _native.hip()
+        counts = numpy.zeros(max(n_units, 1), dtype=numpy.int32)
         needed = ctypes.c_int64()
         _native.check(hip.skm_mapper_last_batch(
-            self.map_result._handle, *[_native.ptr(a, _native.c_i32p) for a in arrays],
+            self.map_result._handle, None, None, None, None, _native.ptr(counts, _native.c_i32p),
             None, 0, ctypes.byref(needed)))
         entries = numpy.zeros(max(needed.value, 1), dtype=numpy.int32)
         _native.check(hip.skm_mapper_last_batch(
             self.map_result._handle, None, None, None, None, None,
             _native.ptr(entries, _native.c_i32p), entries.size, ctypes.byref(needed)))
-        return tuple(a[:n_units] for a in arrays) + (entries[:needed.value],)
+        return counts[:n_units], entries[:needed.value]
 
     def __call__(self, reads_iterator):
         """Run the mapping loop (seekmer/_mapper.pyx:59-105)."""
@@ -302,7 +318,7 @@ class ReadMapper:
             # keep other threads off the handle until they are fetched
             with self.map_result.lock:
                 self.map_batch(batch)
-                _, _, _, _, counts, entries = self.last_batch(batch.count)
+                counts, entries = self.last_tuples(batch.count)
                 ids = numpy.where(entries < 0, ~entries, entries).tolist()
                 bounds = numpy.concatenate([[0], numpy.cumsum(counts)]).tolist()
                 tuples = [tuple(ids[bounds[i]:bounds[i + 1]]) for i in range(batch.count)]

@@ -58,7 +58,7 @@ def _adversarial_reads(seqs, rng, n, read_len):
 
 def _run_gpu(index, bases, offsets, n_units, paired):
     from seekmer_amd import mapper, common
-    result = mapper.MapResult(index)
+    result = mapper.MapResult(index, keep_spans=True)
     rm = mapper.ReadMapper(index, result)
     rm.map_batch(common.ReadBatch(n_units, bases, offsets, paired))
     return result, rm.last_batch(n_units)
@@ -204,6 +204,42 @@ def test_unassigned_slots_are_misses(oracle, native_libs, chr21, chr21_oracle_in
     _compare_tables(oracle, expected, fld, result)
 
 
+def test_table_the_reference_probe_does_not_reach_everywhere(oracle, native_libs, chr21, chr21_oracle_index):
+    """The device probes a bucketised copy of the k-mer table (skm_index_layout), which is
+    the reference's map_kmer exactly when the table is a set the reference's linear probe
+    reaches everywhere -- checked slot by slot at upload.  A table that is not (here: k-mers
+    deleted out of the middle of probe chains, which hides the ones stored behind them, and a
+    k-mer stored a second time) must be probed in the reference's own layout and follow
+    _common.pyx:75-97 to the letter: the hidden k-mers are misses."""
+    rng = np.random.default_rng(53)
+    reads = _adversarial_reads(chr21[1], rng, 6000, 100)
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = len(reads) // 2
+    built = make_product_index(chr21_oracle_index, chr21[0])
+    info = built.device_info()
+    assert info['bucketed'] == 1 and info['slots_unreached'] == 0 and info['kmers_twice'] == 0
+    assert info['bucket_kmers'] == (chr21_oracle_index.kmers['kmer'] != np.uint64(0xFFFFFFFFFFFFFFFF)).sum()
+    kmers = chr21_oracle_index.kmers.copy()
+    invalid = np.uint64(0xFFFFFFFFFFFFFFFF)
+    occupied = np.flatnonzero(kmers['kmer'] != invalid)
+    gone = rng.choice(occupied, occupied.size // 20, replace=False)
+    kmers['kmer'][gone] = invalid
+    kmers['entry'][gone] = 0
+    kmers['offset'][gone] = -1
+    free = np.flatnonzero(kmers['kmer'] == invalid)
+    kmers[free[:50]] = kmers[occupied[1000:1050]]               # (whichever copy the probe meets first wins)
+    tampered = oracle.OracleIndex(kmers, chr21_oracle_index.contigs, chr21_oracle_index.sequences,
+                                  chr21_oracle_index.targets, lengths=chr21_oracle_index.lengths)
+    index = make_product_index(tampered, chr21[0])
+    info = index.device_info()
+    assert info['bucketed'] == 0 and info['slots_unreached'] > 100
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(tampered, bases, offsets, n_units, True, fld)
+    result, units = _run_gpu(index, bases, offsets, n_units, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_quantify_resident_without_classes(oracle, native_libs, chr21, chr21_oracle_index):
     """Nothing mapped: quantify() returns zeros (seekmer/infer.py:106-107), no EM step."""
     from seekmer_amd import infer
@@ -305,7 +341,7 @@ def test_access_counters_equal_the_oracles(oracle, native_libs, chr21, chr21_ora
     fld = np.zeros(2000, dtype=np.int64)
     ostats = oracle.Stats()
     expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld, stats=ostats)
-    result = mapper.MapResult(index)
+    result = mapper.MapResult(index, keep_spans=True)
     result.set_stats(True)
     rm = mapper.ReadMapper(index, result)
     rm.map_batch(common.ReadBatch(n_units, bases, offsets, paired))
