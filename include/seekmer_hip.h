@@ -152,7 +152,8 @@ int skm_mapper_timing(skm_mapper *mapper, double stats[8]);
  * [9]=tuple ids; out[16..30] = scheduler census of the map kernel: rounds, then
  * (chunk executions, lanes) of start, lookup, merge, left, right, emit, scan;
  * out[32..46] = wave-cycle sums: schedule, (unused), then per action, then six
- * phases of the emission. */
+ * phases of the emission.  enable = 2 selects the census build instead: the production code
+ * paths with the census and cycle sums (a profiling aid; its access counters undercount). */
 int skm_mapper_set_stats(skm_mapper *mapper, int enable);
 int skm_mapper_access_stats(skm_mapper *mapper, int64_t out[48]);
 

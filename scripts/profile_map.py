@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--single', action='store_true')
     ap.add_argument('--cache', default='')
     ap.add_argument('--stats', action='store_true')
+    ap.add_argument('--census', action='store_true', help='census build: production paths + cycle sums')
     ap.add_argument('--again', action='store_true', help='map the batch once more without a reset')
     ap.add_argument('--sorted', action='store_true',
                     help='experiment: re-run with the units ordered by their anchor contig')
@@ -49,8 +50,8 @@ def main():
     _native.check(hip.skm_device_upload(0, d_bases, bases.ctypes.data, bases.size))
     _native.check(hip.skm_device_upload(0, d_off, offsets.ctypes.data, offsets.size * 8))
     result = mapper.MapResult(index, keep_spans=args.sorted)
-    if args.stats:
-        result.set_stats(True)
+    if args.stats or args.census:
+        result.set_stats(2 if args.census else 1)
     for rep in range(args.reps):
         result.reset()
         before = result.timing()
@@ -69,7 +70,7 @@ def main():
         print('again (no reset): pack %.3f map %.3f classes %.3f ms sizes %s' % (
             (after['pack_ns'] - before['pack_ns']) * 1e-6, (after['map_ns'] - before['map_ns']) * 1e-6,
             (after['class_ns'] - before['class_ns']) * 1e-6, result.sizes()), flush=True)
-    if args.stats:
+    if args.stats or args.census:
         print(result.access_stats())
     if args.sorted:
         rm = mapper.ReadMapper(index, result)

@@ -141,7 +141,7 @@ struct skm_mapper {
     int64_t first_seen_bound = 0;     // every first_seen in the table is below this
     int64_t last_units = 0, last_ids = 0;
     int64_t host_classes = 0, host_arena_used = 0;
-    bool want_stats = false;
+    int want_stats = 0;               // 0 production, 1 counting build, 2 census build
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
     double t_em_ns = 0, em_iters = 0;          // skm_quant_infer calls on this mapper
     unsigned long long stats_total[48] = {0};
@@ -598,15 +598,15 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
 
     SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
 
-    // launch geometry: persistent blocks of 256 lanes, each with 512 unit contexts in LDS
-    // (~38 KB -> 4 blocks per CU); fewer blocks when the per-context list workspace
+    // launch geometry: persistent blocks of 256 lanes, each with MAP_CONTEXTS unit contexts in LDS
+    // (just under 40 KB -> 4 blocks per CU); fewer blocks when the per-context list workspace
     // (2 lists of max_target_count entries) would not fit the budget
-    constexpr int64_t CONTEXTS = 512;
+    constexpr int64_t CONTEXTS = MAP_CONTEXTS;
     int64_t blocks = std::min<int64_t>((n_units + CONTEXTS - 1) / CONTEXTS, (int64_t)ix->cu_count * MAP_BLOCKS_PER_CU);
     // per context: mask extension words (live + staging, two mates) for slices > 64 targets
     const int64_t ext_words = std::max<int64_t>(0, (ix->d.max_target_count + 63) / 64 - 1);
     SKM_TRY(m->workspace.ensure((size_t)(blocks * CONTEXTS * 4 * ext_words * 2 + 16)));
-    SKM_TRY(m->mate1.ensure((size_t)(blocks * CONTEXTS) * 48));
+    SKM_TRY(m->mate1.ensure((size_t)(blocks * CONTEXTS) * 64 + 64));
     m->grid_blocks = (int)blocks;
     {   // the kernel addresses a block's records with 32-bit byte offsets
         const int64_t per_block = (n_units + blocks - 1) / blocks;
@@ -725,7 +725,7 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     HIP_TRY(pool_stream_acquire(&m->stream));
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void **)&m->pinned, 64 * sizeof(unsigned long long)));
-    m->want_stats = getenv("SKM_MAP_STATS") != nullptr;
+    if (const char *v = getenv("SKM_MAP_STATS")) m->want_stats = v[0] == '2' ? 2 : 1;
     if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "start,lookup,merge,left,right,emit,scan"
         sscanf(v, "%d,%d,%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4],
                &m->vote[5], &m->vote[6]);
@@ -1026,7 +1026,7 @@ extern "C" int skm_mapper_set_stats(skm_mapper *m, int enable)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
     std::lock_guard<std::mutex> lock(m->mu);
-    m->want_stats = enable != 0;
+    m->want_stats = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     for (auto &v : m->stats_total) v = 0;
     return SKM_OK;
 }

@@ -45,6 +45,7 @@ struct MapBatch {
 #endif
 constexpr int MAP_THREADS = SKM_MAP_THREADS;
 constexpr int MAP_BLOCKS_PER_CU = 4;
+constexpr int MAP_CONTEXTS = 480;     // unit contexts per block: 16 words + 7 ring entries each, 4 blocks in 160 KB of LDS
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
@@ -54,7 +55,8 @@ void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs
 // reference probe does not reach
 void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *buckets, uint32_t bucket_mask,
                          uint32_t bucket_shift, unsigned long long *report, hipStream_t stream);
-void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bool stats,
+// stats: 0 production, 1 counting build, 2 census build (skm_map.hip)
+void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, int stats,
                       hipStream_t stream);
 void launch_pack_sequences(const char *bases, int64_t n_bases, uint64_t *seq2, int64_t n_words,
                            hipStream_t stream);

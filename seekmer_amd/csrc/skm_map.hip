@@ -289,11 +289,7 @@ __device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, TSet &se
 // all-pairs with fully unrolled code.  Longer slices, unsorted indices and the
 // counting build take the walks.
 constexpr int LIST_REGS = 16;
-#ifdef SKM_STATS_LIST_FAST          // profiling aid: cycle census of the register paths (counters then undercount)
-#define LIST_FAST(stats) true
-#else
-#define LIST_FAST(stats) (!(stats))
-#endif
+#define LIST_FAST(count) (!(count))
 constexpr int32_t NO_ENTRY = INT32_MIN;      // (would be transcript 2^31-1: cannot occur, n_targets < 2^30)
 constexpr int32_t NO_ENTRY_B = INT32_MIN + 1; // the same for the other side of a comparison: never equal to NO_ENTRY
 
@@ -347,21 +343,24 @@ __device__ __forceinline__ uint32_t keep_common_exact(const int32_t (&a)[LIST_RE
     return keep;
 }
 // The same when no value occurs twice on either side (`twice` of load_list, all but a handful
-// of slices): a position survives iff its value occurs in b -- 256 compares accumulated as lane
-// masks on the scalar side, two instructions apiece and no carry chains.
+// of slices): a position survives iff its value occurs in b.  All pairs on the vector ALU only:
+// the smallest a[i] ^ b[j] over j is 0 iff a[i] is in b -- v_xor + half a v_min3_u32 per pair,
+// no lane masks through scalar registers (compare + s_or was two instructions per pair and
+// compare + add-with-carry costs two wait states per pair on gfx950).
 __device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS],
                                                 bool twice)
 {
     if (twice) return keep_common_exact(a, b);
-    uint32_t keep = 0;
+    uint32_t dropped = 0;
 #pragma unroll
     for (int i = 0; i < LIST_REGS; ++i) {
-        bool present = false;
+        uint32_t nearest = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < LIST_REGS; ++j) present |= a[i] == b[j];
-        keep |= present ? (1u << i) : 0u;
+        for (int j = 0; j < LIST_REGS; j += 2)
+            nearest = min(nearest, min((uint32_t)(a[i] ^ b[j]), (uint32_t)(a[i] ^ b[j + 1])));
+        dropped |= min(nearest, 1u) << i;                 // 1 = a[i] is not in b
     }
-    return keep;
+    return ~dropped & 0xffffu;
 }
 
 // KMerIndex._filter_on_contig, _common.pyx:185-235: two-pointer merge of the
@@ -438,11 +437,21 @@ __device__ __forceinline__ uint32_t ref_code(uint32_t ref8, int i) { return (ref
 
 // sift4_align_left, _mapper.pyx:404-445 (the query cursor starts one base
 // short of the reference cursor, lines 406-408)
-__device__ __forceinline__ int sift4_left(uint32_t ref8, const ReadView &r, int offset)
+__device__ __forceinline__ QWindow left_window(const ReadView &r, int offset)
 {
     QWindow q;
     q.base = offset > 0 ? offset - 1 : 0;
     read_window16(r, q.base, q.codes, q.acgt);
+    return q;
+}
+// the windows of the two closing checks (read bases 0..7 and len-8..len-1, _mapper.pyx:270-275,
+// :335-343) from the copy kept with the context: 8 codes (16 bits) + 8 "is ACGT" bits each
+__device__ __forceinline__ QWindow edge_window(uint32_t codes16, uint32_t acgt8, int base)
+{
+    return QWindow{codes16 << 16, acgt8 << 8, base};
+}
+__device__ __forceinline__ int sift4_left(uint32_t ref8, const QWindow &q, int offset)
+{
     int rc = ALIGN_LENGTH - 1;
     int qc = offset + ALIGN_LENGTH - 2;
     int distance = 0;
@@ -469,11 +478,15 @@ __device__ __forceinline__ int sift4_left(uint32_t ref8, const ReadView &r, int 
 }
 
 // sift4_align_right, _mapper.pyx:452-493
-__device__ __forceinline__ int sift4_right(uint32_t ref8, const ReadView &r, int offset)
+__device__ __forceinline__ QWindow right_window(const ReadView &r, int offset)
 {
     QWindow q;
     q.base = offset;
     read_window16(r, q.base, q.codes, q.acgt);
+    return q;
+}
+__device__ __forceinline__ int sift4_right(uint32_t ref8, const QWindow &q, int offset, int read_len)
+{
     int rc = 0;
     int qc = offset;
     int distance = 0;
@@ -482,7 +495,7 @@ __device__ __forceinline__ int sift4_right(uint32_t ref8, const ReadView &r, int
         if (rc != qc - offset) { rc = max(qc - offset, rc); qc = rc + offset; }
 #pragma unroll
         for (int i = 0; i < MAX_OFFSET; ++i) {
-            if (qc + i < offset + ALIGN_LENGTH + 1 && qc + i < r.len
+            if (qc + i < offset + ALIGN_LENGTH + 1 && qc + i < read_len
                     && q.match(ref_code(ref8, rc), qc + i)) {
                 distance += i - 1; qc += i - 1; rc -= 1;
                 break;
@@ -618,10 +631,10 @@ enum : int { ST_IDLE = 0, ST_NEW,
 enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_ACTIONS };
 constexpr int SCAN_ROUNDS = 4;
 
-constexpr int NCTX = 512;             // unit contexts per block (LDS)
+constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
 
-struct Mate1 {                        // span and target set of mate 1, parked in HBM
+struct alignas(64) Mate1 {            // span and target set of mate 1, parked in HBM: one sector per slot
     int32_t begin, end, anchor_entry, anchor_offset, n, len, set_start, set_length_fwd;
     uint64_t word0;
 };
@@ -646,12 +659,16 @@ __device__ __forceinline__ Coord lookup_kmer(const DevIndex &ix, uint64_t kmer, 
     return map_kmer<STATS>(ix, kmer, st);
 }
 
-// STATS: the counting build (access counters, scheduler census; always the reference's table
-// layout).  BUCKETS: the index carries a bucket table (every built index does).
+// <false, *>: the production kernels (BUCKETS: the index carries a bucket table, as every built
+// index does).  <true, false>: the counting build -- every access of the reference's algorithm is
+// performed in the reference's table layout and counted (these counts are the algorithmic bytes),
+// plus the scheduler census.  <true, true>: the census build, a profiling aid -- the production
+// code paths with the scheduler census and cycle stamps (its access counters undercount).
 template <bool STATS, bool BUCKETS>
 __global__ void __launch_bounds__(MAP_THREADS, SKM_MAP_WAVES_PER_EU)
 map_units_kernel(DevIndex ix, MapBatch b)
 {
+    constexpr bool COUNT = STATS && !BUCKETS;
     __shared__ uint32_t fld_lds[FLD_WINDOW];
     // contexts, structure of arrays
     __shared__ int32_t c_state[NCTX], c_unit[NCTX], c_begin[NCTX], c_end[NCTX], c_aentry[NCTX],
@@ -659,6 +676,12 @@ map_units_kernel(DevIndex ix, MapBatch b)
     // c_look: the 16 read bases (2-bit codes) of the aligned half word that holds base c_scan,
     // so that rolling the first k-mer forward touches the read record once per 16 bases
     __shared__ uint32_t c_kmer_lo[NCTX], c_kmer_hi[NCTX], c_mask_lo[NCTX], c_mask_hi[NCTX], c_look[NCTX];
+    // c_edge: the first 8 (low half) and the last 8 (high half) bases of the current read as
+    // 2-bit codes -- what the two closing checks compare (_mapper.pyx:270-275, :335-343); their
+    // "is ACGT" bits ride in bits 20-27 of c_scan (head) and c_len (tail).  The read record
+    // is in L2 for ~10 us after a touch and a unit lives 15 rounds: without the copy every
+    // closing check fetches the record's sector again.
+    __shared__ uint32_t c_edge[NCTX];
     // one MPMC ring per action: entry = context | 0x8000 once written, 0 while empty
     __shared__ uint16_t ring[N_ACTIONS][NCTX];
     __shared__ uint32_t q_head[N_ACTIONS], q_tail[N_ACTIONS], next_unit, done_units, busy, stalled;
@@ -765,7 +788,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
             const int64_t u = block_first + c_unit[c];
             Span span{c_begin[c], c_end[c], Coord{c_aentry[c], c_aoffset[c]}, (int32_t)((uint32_t)word >> 10)};
             uint32_t look = c_look[c];
-            int scan_i = c_scan[c];
+            uint32_t edge = c_edge[c];
+            const uint32_t scan_word = (uint32_t)c_scan[c], len_word = (uint32_t)c_len[c];
+            int scan_i = (int)(scan_word & 0xffffffu);
+            uint32_t head_acgt = scan_word >> 24, tail_acgt = len_word >> 24;
             uint64_t kmer = ((uint64_t)c_kmer_hi[c] << 32) | c_kmer_lo[c];
             uint64_t *const ext1 = ws_block + (size_t)c * 4 * (size_t)ext_words;
             uint64_t *const ext2 = ext1 + 2 * (size_t)ext_words;
@@ -773,7 +799,17 @@ map_units_kernel(DevIndex ix, MapBatch b)
                      ((uint64_t)c_mask_hi[c] << 32) | c_mask_lo[c], mate ? ext2 : ext1, ext_words};
             const uint32_t first_read = b.paired ? 2u * (uint32_t)c_unit[c] : (uint32_t)c_unit[c];
             ReadView rv{block_records, (first_read + (uint32_t)mate) * record_bytes, b.words_per_read,
-                        c_len[c]};      // (the length is kept with the context: saves touching the record)
+                        (int)(len_word & 0xffffffu)};   // (the length is kept with the context: saves touching the record)
+            // first and last 8 bases of a read that is about to be mapped -> edge, head_acgt, tail_acgt
+            auto keep_edges = [&]() {
+                uint32_t codes, acgt;
+                read_window16(rv, 0, codes, acgt);
+                edge = codes >> 16;
+                head_acgt = acgt >> 8;
+                read_window16(rv, rv.len - ALIGN_LENGTH, codes, acgt);
+                edge |= codes & 0xffff0000u;
+                tail_acgt = acgt >> 8;
+            };
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
             if (valid && action == A_START) {
@@ -789,6 +825,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     kmer = read_kmer(rv, 0);
                     scan_i = K;
                     look = read_half(rv, scan_i >> 4);
+                    keep_edges();
                     state = Y_FIRST;
                 }
             } else if (valid && action == A_LOOKUP) {
@@ -903,7 +940,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 }
             } else if (valid && action == A_MERGE) {
                 // ---------------------------------- the one _filter_on_contig site
-                const bool ok = filter_on_contig<STATS>(ix, set, span, &ls);
+                const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
                 if (state == M_LJ) {
                     if (ok) state = N_LEFT;
                     else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
@@ -928,8 +965,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     span.anchor.offset -= forward ? span.begin : -span.begin;
                     at = 0;
                 }
+                // (the closing check compares read bases 0..7: kept with the context)
+                const QWindow q = in_loop ? left_window(rv, at) : edge_window(edge & 0xffffu, head_acgt, 0);
                 const int shift = sift4_left(in_loop ? contig8_edge<STATS>(ix, span.anchor, true, &ls)
-                                                     : contig8<STATS>(ix, span.anchor, true, &ls), rv, at);
+                                                     : contig8<STATS>(ix, span.anchor, true, &ls), q, at);
                 if (!in_loop) {
                     if (shift == INVALID_SHIFT) span.n = 0;
                     state = N_RIGHT_ENTER;
@@ -963,8 +1002,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     span.anchor.offset += forward ? rest : -rest;
                     at = rv.len - ALIGN_LENGTH;
                 }
+                // (the closing check compares the last 8 read bases: kept with the context)
+                const QWindow q = in_loop ? right_window(rv, at) : edge_window(edge >> 16, tail_acgt, at);
                 const int shift = sift4_right(in_loop ? contig8_edge<STATS>(ix, span.anchor, false, &ls)
-                                                      : contig8<STATS>(ix, span.anchor, false, &ls), rv, at);
+                                                      : contig8<STATS>(ix, span.anchor, false, &ls), q, at, rv.len);
                 if (!in_loop) {
                     if (shift == INVALID_SHIFT) span.n = 0;
                     state = N_AFTER;
@@ -1005,7 +1046,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         const Span s2 = span;
                         if (STATS) asm volatile("" ::"v"(m1.word0));
                         phase(0);
-                        if (!intersect<STATS>(ix, set1, s1, set, s2)) {
+                        if (!intersect<COUNT>(ix, set1, s1, set, s2)) {
                             s1.n = 0;
                             s1.begin = 0;
                             s1.end = -K;
@@ -1053,7 +1094,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     const bool fits = off + n_out <= b.ids_capacity;
                     int i = 0;
                     int words = n_out ? set.words() : 0;
-                    if (LIST_FAST(STATS) && n_out && set.length <= LIST_REGS) {      // short list: one round trip
+                    if (LIST_FAST(COUNT) && n_out && set.length <= LIST_REGS) {      // short list: one round trip
                         int32_t e[LIST_REGS];
                         load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, e);
 #pragma unroll
@@ -1115,7 +1156,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         // :283-284 re-anchors on the k-mer at span.end.  Straight after the
                         // first hit that is the k-mer just looked up and the anchor is its
                         // result, so the repeat is skipped (the counting build performs it).
-                        if (anchored && !STATS) {
+                        if (anchored && !COUNT) {
                             state = N_RIGHT;
                         } else {
                             kmer = read_kmer(rv, span.end);
@@ -1154,6 +1195,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         kmer = read_kmer(rv, 0);
                         scan_i = K;
                         look = read_half(rv, scan_i >> 4);
+                        keep_edges();
                         state = Y_FIRST;
                     } else {
                         state = ST_UNIT_DONE;                 // mate 2 shorter than k: unmapped
@@ -1172,8 +1214,9 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 c_aentry[c] = span.anchor.entry;
                 c_aoffset[c] = span.anchor.offset;
                 c_look[c] = look;
-                c_scan[c] = scan_i;
-                c_len[c] = rv.len;
+                c_edge[c] = edge;
+                c_scan[c] = (int32_t)((uint32_t)scan_i | (head_acgt << 24));
+                c_len[c] = (int32_t)((uint32_t)rv.len | (tail_acgt << 24));
                 c_kmer_lo[c] = (uint32_t)kmer;
                 c_kmer_hi[c] = (uint32_t)(kmer >> 32);
                 c_tstart[c] = set.start;
@@ -1255,11 +1298,13 @@ void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_r
                        bases, offsets, n_reads, words_per_read, record_words, records);
 }
 
-void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, bool stats,
+void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, int stats,
                       hipStream_t stream)
 {
     if (b.n_units == 0) return;
-    if (stats)
+    if (stats == 2 && ix.buckets)
+        hipLaunchKernelGGL((map_units_kernel<true, true>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
+    else if (stats)
         hipLaunchKernelGGL((map_units_kernel<true, false>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
     else if (ix.buckets)
         hipLaunchKernelGGL((map_units_kernel<false, true>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);

@@ -240,7 +240,7 @@ class MapResult:
             self._handle, d_bases, d_offsets, n_units, int(bool(paired)), max_read_len))
 
     def set_stats(self, enable):
-        _native.check(_native.hip().skm_mapper_set_stats(self._handle, int(bool(enable))))
+        _native.check(_native.hip().skm_mapper_set_stats(self._handle, int(enable)))
 
     def access_stats(self):
         out = (ctypes.c_int64 * 48)()
