@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: paired reads/s mapped + quantified (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 1|3|4]
 
 One "step" = one pass of the infer hot path over one resident batch:
 pack -> map -> class counting -> effective lengths -> EM to the reference's
-stopping rule -> TPM, for `--pairs` synthetic 2x100 read pairs per GPU against
-the synthetic ~190k-transcript index (BASELINE.json configs[1]; the ENSEMBL
-cDNA named there is not available offline, SURVEY.md 8(d) defines the seeded
-stand-in).  Inputs are resident in HBM when the timed region starts.  For
-N > 1 (launched by torch.distributed.run, one rank per GPU) reads shard across
-ranks with no collective while mapping and one RCCL all-reduce of f64[T] per
-EM step; rank 0 prints ONE JSON line.
+stopping rule -> TPM, against the synthetic ~190k-transcript index (the ENSEMBL
+cDNA BASELINE.json names is not available offline; SURVEY.md 8(d) defines the
+seeded stand-in).  Inputs are resident in HBM when the timed region starts.
+
+  --config 1 (default)  BASELINE configs[1]: 10 M 2x100 bp pairs per GPU
+  --config 3            BASELINE configs[3]: 50 M single-end 150 bp reads (-s)
+  --config 4            BASELINE configs[4]: 20 M 2x100 bp pairs + `-b 100` (the step also draws
+                        100 multinomial resamples of the class table and runs the EM on each)
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) reads shard
+across ranks with no collective while mapping and one RCCL all-reduce of
+f64[T] per EM step; rank 0 prints ONE JSON line.  At N = 1 and --config 1 the
+line also carries `e2e`: the same workload timed from host arrays (PCIe
+inclusive) and from FASTQ text -- neither is `value`.
 """
 import argparse
 import ctypes
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,24 +35,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PMC_SUMMARY = os.path.join('profiles', 'r02_pmc_map.json')     # rocprofv3 --pmc passes of the map kernel
 
 
 def log(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units):
+def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units, paired, bootstraps=0):
     """The CPU oracle ("port" of the reference algorithm) on a bounded sample of the same
-    workload: map + class counting + effective lengths + EM.  Timed twice: one thread, and
-    the map phase sharded over all the host cores this process may use (the oracle's C
-    mapper releases the GIL; classes are then counted in shard order, EM on one core) --
-    `value` is the all-core figure, the single-thread one is quoted in `sample`."""
+    workload: map + class counting + effective lengths + EM (+ `bootstraps` resamples, each a
+    numpy multinomial draw and an EM from the main estimate, as seekmer/infer.py:108-111).
+    Timed twice: one thread, and the map phase sharded over all the host cores this process may
+    use (the oracle's C mapper releases the GIL; classes are then counted in shard order, EM on
+    one core) -- `value` is the faster, the other is quoted in `sample`."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     from seekmer_amd import synth
     oindex = O.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
                            lengths=np.diff(tx_offsets))
-    bases, offsets = synth.reads(seed, pool, tx_offsets, 0, sample_units, read_len, True)
+    bases, offsets = synth.reads(seed, pool, tx_offsets, 0, sample_units, read_len, paired)
+    mates = 2 if paired else 1
 
     def quantify(results, fld):
         classes = O.Classes()
@@ -51,14 +63,24 @@ def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units):
             classes.update(r)
         class_map, class_count = classes.summarize()
         eff = O.effective_lengths(fld, oindex.lengths)
-        return O.quantify(eff, class_map, class_count)
+        tpm, iters = O.quantify(eff, class_map, class_count)
+        boot_s = 0.0
+        if bootstraps:
+            rng = np.random.default_rng(seed)
+            x0 = tpm / tpm.sum()
+            t0 = time.perf_counter()
+            for _ in range(bootstraps):
+                draw = rng.multinomial(int(class_count.sum()), class_count / class_count.sum()).astype('f8')
+                O.em(x0, eff, class_map, draw)
+            boot_s = time.perf_counter() - t0
+        return tpm, iters, boot_s
 
     t0 = time.perf_counter()
     fld = np.zeros(2000, dtype=np.int64)
-    result = O.map_batch(oindex, bases, offsets, sample_units, True, fld)
+    result = O.map_batch(oindex, bases, offsets, sample_units, paired, fld)
     t_map1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    tpm, iters = quantify([result], fld)
+    tpm, iters, boot_s = quantify([result], fld)
     t_quant = time.perf_counter() - t0
     del result
 
@@ -68,11 +90,11 @@ def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units):
 
     def shard(k):
         first, last = min(k * per, sample_units), min((k + 1) * per, sample_units)
-        lo, hi = offsets[2 * first], offsets[2 * last]
-        sub_offsets = (offsets[2 * first:2 * last + 1] - lo).copy()
+        lo, hi = offsets[mates * first], offsets[mates * last]
+        sub_offsets = (offsets[mates * first:mates * last + 1] - lo).copy()
         sub_bases = np.concatenate([bases[lo:hi], np.zeros(1, np.uint8)])
         sub_fld = np.zeros(2000, dtype=np.int64)
-        return O.map_batch(oindex, sub_bases, sub_offsets, last - first, True, sub_fld), sub_fld
+        return O.map_batch(oindex, sub_bases, sub_offsets, last - first, paired, sub_fld), sub_fld
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -80,21 +102,117 @@ def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units):
     t_mapn = time.perf_counter() - t0
     fld_n = np.sum([p[1] for p in parts], axis=0)
     assert np.array_equal(fld_n, fld)           # sharding does not change the integer results
-    t0 = time.perf_counter()
-    quantify([p[0] for p in parts], fld_n)
-    t_quantn = time.perf_counter() - t0
     single = sample_units / (t_map1 + t_quant)
-    multi = sample_units / (t_mapn + t_quantn)
-    return {
+    multi = sample_units / (t_mapn + t_quant)   # (classes + EM timed once: the same work either way)
+    unit = 'pairs/s' if paired else 'reads/s'
+    out = {
         # the faster of the two runs, with the threads it used (the oracle restates the reference's
         # per-read malloc'd lists, which limits its thread scaling)
-        'value': max(single, multi), 'unit': 'pairs/s', 'cores': cores if multi > single else 1,
+        'value': max(single, multi), 'unit': unit, 'cores': cores if multi > single else 1,
         'kind': 'port', 'single_thread_value': single, 'all_core_value': multi, 'host_cores': cores,
-        'sample': '%d pairs of the same read set; 1 thread: oracle map %.2fs (%.0f pairs/s) + classes/EM %.2fs '
-                  '(%d EM steps); %d threads: map %.2fs (%.0f pairs/s) + classes/EM %.2fs'
-                  % (sample_units, t_map1, sample_units / t_map1, t_quant, iters, cores, t_mapn,
-                     sample_units / t_mapn, t_quantn),
+        'sample': '%d %s of the same read set; 1 thread: oracle map %.2fs (%.0f %s) + classes/EM%s %.2fs '
+                  '(%d EM steps); %d threads: map %.2fs (%.0f %s) + the same classes/EM'
+                  % (sample_units, 'pairs' if paired else 'reads', t_map1, sample_units / t_map1, unit,
+                     ' incl. %d bootstraps' % bootstraps if bootstraps else '', t_quant, iters, cores,
+                     t_mapn, sample_units / t_mapn, unit),
     }
+    if bootstraps:
+        out['bootstraps_per_s'] = bootstraps / boot_s
+    return out
+
+
+def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, passes=3):
+    """configs[1] once more from outside the GPU (N = 1 only): (a) the batch in page-locked host
+    arrays, handed over in `--e2e-batches` pieces through skm_mapper_map_batch_async (copy of
+    piece i+1 under the kernels of piece i), then the resident quantification; (b) the same reads
+    as FASTQ text on the host's RAM disk, parsed by the native reader's parallel engine into
+    page-locked slabs and handed over the same way.  Best of `passes`."""
+    from seekmer_amd import common, infer, mapper, synth
+    out = {}
+    read_len, pieces = args.read_len, max(1, args.e2e_batches)
+    result = mapper.MapResult(index, device=device)
+    rm = mapper.ReadMapper(index, result)
+    # ---- (a) host arrays -> TPM
+    n_bytes = bases.size
+    p_bases = hip.skm_pinned_alloc(n_bytes)
+    p_offsets = hip.skm_pinned_alloc(offsets.size * 8)
+    if not p_bases or not p_offsets:
+        raise RuntimeError('cannot page-lock %d bytes of host memory' % (n_bytes + offsets.size * 8))
+    h_bases = np.ctypeslib.as_array(ctypes.cast(p_bases, ctypes.POINTER(ctypes.c_uint8)), (n_bytes,))
+    h_offsets = np.ctypeslib.as_array(ctypes.cast(p_offsets, _native.c_i64p), (offsets.size,))
+    h_bases[:] = bases
+    h_offsets[:] = offsets
+    cut = [n_units * k // pieces for k in range(pieces + 1)]
+
+    def from_host():
+        result.reset()
+        t0 = time.perf_counter()
+        for k in range(pieces):
+            sub = common.ReadBatch(cut[k + 1] - cut[k], h_bases, h_offsets[2 * cut[k]:2 * cut[k + 1] + 1], True,
+                                   first_unit=cut[k])
+            rm.map_batch_async(sub)
+        result.sync()
+        t_map = time.perf_counter() - t0
+        infer.quantify_resident(result)
+        return t_map, time.perf_counter() - t0
+
+    best = min((from_host() for _ in range(passes + 1)), key=lambda t: t[1])
+    out['pcie_inclusive'] = {
+        'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
+        'host_bytes': int(n_bytes + offsets.size * 8), 'GBps_over_pcie': (n_bytes + offsets.size * 8) / best[0] / 1e9,
+        'how': '%d pairs in page-locked host arrays (skm_pinned_alloc), %d batches through '
+               'skm_mapper_map_batch_async, then skm_quant_infer; best of %d passes' % (n_units, pieces, passes)}
+    classes_host = result.sizes()
+    hip.skm_pinned_free(p_bases)
+    hip.skm_pinned_free(p_offsets)
+    # ---- (b) FASTQ text -> TPM
+    ram = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+    need = 2 * n_units * (2 * read_len + 19)
+    if shutil.disk_usage(ram).free < need * 1.2:
+        ram = tempfile.gettempdir()
+    if shutil.disk_usage(ram).free < need * 1.2:
+        out['fastq_inclusive'] = None
+        return out
+    folder = tempfile.mkdtemp(prefix='skm_bench_', dir=ram)
+    try:
+        p1, p2 = os.path.join(folder, 'r_1.fastq'), os.path.join(folder, 'r_2.fastq')
+        t0 = time.perf_counter()
+        synth.write_fastq(bases, n_units, read_len, True, p1, p2)
+        log('wrote %.1f GB of FASTQ text to %s in %.1fs' % (need / 1e9, folder, time.perf_counter() - t0))
+        threads = max(1, min(args.parse_threads, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity')
+                                                  else os.cpu_count() or 1)))
+        batch_units = (n_units + pieces - 1) // pieces
+
+        def parse_only():
+            t0 = time.perf_counter()
+            count = 0
+            for batch in common.NativeReadFeeder([p1, p2], True, batch_units=batch_units, threads=threads, pinned=True):
+                count += batch.count
+            assert count == n_units
+            return time.perf_counter() - t0
+
+        def from_fastq():
+            result.reset()
+            t0 = time.perf_counter()
+            feeder = common.NativeReadFeeder([p1, p2], True, batch_units=batch_units, threads=threads, pinned=True)
+            rm(feeder)                       # the reference's mapping loop: every batch handed over, then sync
+            t_map = time.perf_counter() - t0
+            infer.quantify_resident(result)
+            return t_map, time.perf_counter() - t0, feeder.parallel
+
+        t_parse = min(parse_only() for _ in range(2))
+        best = min((from_fastq() for _ in range(passes + 1)), key=lambda t: t[1])
+        assert result.sizes() == classes_host           # same classes as from the host arrays
+        out['fastq_inclusive'] = {
+            'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
+            'parse_only': n_units / t_parse, 'text_GBps': need / best[0] / 1e9, 'parse_threads': threads,
+            'parallel_engine': bool(best[2]),
+            'how': 'two FASTQ files (%d bytes per record, RAM disk) -> NativeReadFeeder(threads=%d, pinned) in '
+                   '%d batches -> skm_mapper_map_batch_async -> skm_quant_infer; best of %d passes'
+                   % (2 * read_len + 19, threads, pieces, passes)}
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    return out
 
 
 def main():
@@ -102,13 +220,27 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', type=int, default=1, choices=(1, 3, 4), help='BASELINE.json configs[] index')
     ap.add_argument('--genes', type=int, default=20000, help='synthetic genes (20000 -> ~190k tx)')
-    ap.add_argument('--pairs', type=int, default=10_000_000, help='read pairs per GPU per step')
-    ap.add_argument('--read-len', type=int, default=100)
+    ap.add_argument('--pairs', type=int, default=0, help='units per GPU per step (default: the config\'s size)')
+    ap.add_argument('--read-len', type=int, default=0)
+    ap.add_argument('--bootstraps', type=int, default=-1, help='-b N inside the step (default: 100 for --config 4)')
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--cpu-sample', type=int, default=1_000_000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--e2e-batches', type=int, default=10)
+    ap.add_argument('--parse-threads', type=int, default=12)
+    ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
     args = ap.parse_args()
+    shape = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100)}
+    n_units, read_len, paired, bootstraps = shape[args.config]
+    n_units = args.pairs or n_units
+    args.read_len = read_len = args.read_len or read_len
+    bootstraps = bootstraps if args.bootstraps < 0 else args.bootstraps
+    unit_name = 'pairs' if paired else 'reads'
+    if bootstraps and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        raise SystemExit('configs[4] (-b N) is a single-GPU configuration: bootstraps resample the merged table')
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -124,7 +256,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)   # rendezvous / barrier only
 
-    from seekmer_amd import _native, index_builder, infer, mapper, synth
+    from seekmer_amd import _native, common, index_builder, infer, mapper, parallel, synth
     hip = _native.hip()
     device = local_rank
     if os.environ.get('SKM_BENCH_ONE_DEVICE') == '1':      # rehearsal of the N > 1 path on a 1-GPU box
@@ -135,20 +267,20 @@ def main():
     # ---------------- setup (untimed): transcriptome, index, reads -> HBM
     t0 = time.perf_counter()
     ids, pool, tx_offsets = synth.transcriptome(args.seed, args.genes)
-    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    # one rank builds the index, the others map the container it wrote (2.2 GB, memory-mapped)
+    index = parallel.shared_index(lambda: index_builder.build_pooled(ids, pool, tx_offsets), rank, world,
+                                  barrier=(dist.barrier if dist is not None else None),
+                                  cache=args.index_cache or None)
     n_tx = len(ids)
-    log('rank %d: %d transcripts, %d k-mer slots, index built in %.1fs'
+    log('rank %d: %d transcripts, %d k-mer slots, index ready in %.1fs'
         % (rank, n_tx, index.kmers.size, time.perf_counter() - t0))
-    n_units = args.pairs
-    bases, offsets = synth.reads(args.seed, pool, tx_offsets, rank * n_units, n_units,
-                                 args.read_len, True)
+    bases, offsets = synth.reads(args.seed, pool, tx_offsets, rank * n_units, n_units, read_len, paired)
     index.device_handle(device)
     d_bases, d_offsets = ctypes.c_void_p(), ctypes.c_void_p()
     _native.check(hip.skm_device_malloc(device, bases.size, ctypes.byref(d_bases)))
     _native.check(hip.skm_device_malloc(device, offsets.size * 8, ctypes.byref(d_offsets)))
     _native.check(hip.skm_device_upload(device, d_bases, bases.ctypes.data, bases.size))
     _native.check(hip.skm_device_upload(device, d_offsets, offsets.ctypes.data, offsets.size * 8))
-    lengths = np.ascontiguousarray(index.transcripts['length'], dtype='f8')
     result = mapper.MapResult(index, device=device)
     comm_id = None
     force_comm = world == 1 and os.environ.get('SKM_FORCE_COMM') == '1'   # 1-rank RCCL rehearsal
@@ -168,9 +300,13 @@ def main():
     comm = ctypes.c_void_p()
     if comm_id is not None:                # one communicator per process, reused by every step
         _native.check(hip.skm_comm_create(device, comm_id, rank, world, ctypes.byref(comm)))
+    rccl_ranks = 0
+    if comm:
+        n = ctypes.c_int(0)
+        _native.check(hip.skm_comm_count(comm, ctypes.byref(n)))
+        rccl_ranks = n.value
 
-    state = {}
-
+    state = {'boot_s': 0.0, 'boot_iters': 0}
     stage = {}
     profile_stages = os.environ.get('SKM_BENCH_PROFILE') in ('1', '2')   # 2: host wall per call, no syncs
     profile_sync = os.environ.get('SKM_BENCH_PROFILE') == '1'
@@ -186,18 +322,31 @@ def main():
         t = time.perf_counter()
         result.reset()
         t = mark('reset', t)
-        result.map_resident(d_bases, d_offsets, n_units, True, args.read_len)
+        result.map_resident(d_bases, d_offsets, n_units, paired, read_len)
         t = mark('map_batch', t)
         before = result.timing()
         # fragment lengths (RCCL all-reduce over the ranks) -> effective lengths -> start
         # vector -> EM -> TPM: one native call on the resident class table
-        tpm, iters = infer.quantify_resident(result, comm=comm if comm else None, return_iters=True)
+        tpm, iters, eff = infer.quantify_resident(result, comm=comm if comm else None, return_iters=True,
+                                                  return_effective_lengths=True)
         t = mark('quantify', t)
         after = result.timing()
         state['em'] = {'em_ns': after['em_ns'] - before['em_ns'],
                        'iterations': after['em_iterations'] - before['em_iterations']}
         state['tpm'] = tpm
         state['iters'] = iters
+        if bootstraps:                     # `-b N` (seekmer/infer.py:79-82): resample + EM from the main estimate
+            t_b = time.perf_counter()
+            quant = infer._QuantHandle.from_map_result(result, n_tx)
+            if comm:
+                _native.check(hip.skm_quant_set_comm(quant.handle, comm))
+            x0 = tpm / tpm.sum()
+            out, _, it = quant.bootstrap(bootstraps, args.seed, x0, eff)
+            state['boot_tpm'] = [infer._tpm(row) for row in out]
+            quant.close()
+            state['boot_s'] += time.perf_counter() - t_b
+            state['boot_iters'] += int(it.sum())
+            mark('bootstrap', t)
 
     def barrier():
         if dist is not None:
@@ -206,6 +355,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    state['boot_s'], state['boot_iters'] = 0.0, 0
     t_before = result.timing()
     barrier()
     t0 = time.perf_counter()
@@ -213,24 +363,34 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    em_steps_check = None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        # every rank must have run the same number of EM steps (each holds one all-reduce): a
+        # mismatch would mean the redundantly judged stopping rule diverged between ranks
+        lo = torch.tensor([state['iters']], dtype=torch.int64)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        em_steps_check = {'min_over_ranks': int(lo[0]), 'max_over_ranks': int(hi[0])}
+        if int(lo[0]) != int(hi[0]):
+            raise SystemExit('EM step counts differ between ranks: %s' % em_steps_check)
     t_after = result.timing()
     if profile_stages and rank == 0:
         log('stage ms per step: ' + ', '.join('%s %.2f' % (k, 1e3 * v / (args.steps + args.warmup))
                                               for k, v in stage.items()))
 
-    # ---------------- roofline of the dominant kernel (map_units_kernel)
+    # ---------------- roofline of the dominant kernel
     launches = t_after['batches'] - t_before['batches']
     map_ns = (t_after['map_ns'] - t_before['map_ns']) / max(launches, 1)
     pack_ns = (t_after['pack_ns'] - t_before['pack_ns']) / max(launches, 1)
     class_ns = (t_after['class_ns'] - t_before['class_ns']) / max(launches, 1)
-    result.set_stats(True)                 # instrumented build, untimed: access counts per launch
+    result.set_stats(True)                 # counting build, untimed: access counts per launch
     result.reset()
-    result.map_resident(d_bases, d_offsets, n_units, True, args.read_len)
+    result.map_resident(d_bases, d_offsets, n_units, paired, read_len)
     st = result.access_stats()
     result.set_stats(False)
     algorithmic = (st['read_bases'] + 16 * st['slots'] + 48 * st['contig_reads']
@@ -238,23 +398,29 @@ def main():
                    + 4 * st['tuple_ids'])
     achieved = algorithmic / map_ns if map_ns else 0.0          # bytes/ns = GB/s
     sizes = result.sizes()
-    # HBM traffic of the same launch from the PMC passes (FETCH_SIZE + WRITE_SIZE, rocprofv3,
-    # separate --pmc runs, profiles/r01_i_pmc_map.json); only quoted for the workload it was taken on
-    traffic, miss_rate = None, None
+    em_bytes = int(sizes[1] * 28 + sizes[0] * 12 + n_tx * 40)     # B_em per EM step
+    # HBM traffic of the map launch: NOT measured by this run (a rocprofv3 --pmc pass is not
+    # something a benchmark can do to itself) -- quoted from the PMC passes of the same build over
+    # the same workload (FETCH_SIZE + WRITE_SIZE, separate --pmc runs, summary committed in
+    # profiles/), and only when this run IS that workload
+    traffic, traffic_source, miss_rate = None, None, None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_i_pmc_map.json')) as f:
+        with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             pmc = json.load(f)
-        if args.genes == 20000 and n_units == 10_000_000 and args.read_len == 100:
+        if args.config == 1 and args.genes == 20000 and n_units == 10_000_000 and read_len == 100:
             traffic = pmc['derived']['hbm_traffic_bytes']
+            traffic_source = 'quoted from %s (rocprofv3 --pmc passes of this build on this workload), ' \
+                             'not measured by this run' % PMC_SUMMARY
             miss_rate = pmc['per_launch']['TCC_MISS_sum'] / (map_ns * 1e-9)
     except (OSError, KeyError, ValueError):
         pass
 
     if rank == 0:
+        total_units = world * n_units * args.steps
         line = {
-            'metric': 'paired reads/sec mapped+quantified',
-            'value': world * n_units * args.steps / elapsed,
-            'unit': 'pairs/s',
+            'metric': 'paired reads/sec mapped+quantified' if paired else 'reads/sec mapped+quantified (single-end)',
+            'value': total_units / elapsed,
+            'unit': '%s/s' % unit_name,
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
@@ -265,19 +431,19 @@ def main():
             'dtype': 'u64+f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'configs[1]: synthetic ~190k-tx index (stand-in for ENSEMBL GRCh38 cDNA), '
-                            '%d 2x%dbp synthetic pairs per GPU, map+classes+EM to the reference stop rule'
-                            % (n_units, args.read_len),
+                'workload': 'configs[%d]: synthetic ~190k-tx index (stand-in for ENSEMBL GRCh38 cDNA), '
+                            '%d %s synthetic %s per GPU, map+classes+EM to the reference stop rule%s'
+                            % (args.config, n_units, ('2x%dbp' if paired else '%dbp single-end') % read_len,
+                               unit_name, ' + %d bootstraps (-b)' % bootstraps if bootstraps else ''),
                 'transcripts': n_tx, 'kmer_slots': int(index.kmers.size),
-                'pairs_per_gpu': n_units, 'read_len': args.read_len,
+                'units_per_gpu': n_units, 'read_len': read_len, 'paired': paired,
                 'classes': sizes[0], 'class_map_rows': sizes[1],
                 'em_iterations': int(state['iters']),
                 'em_iters_per_s': state['em']['iterations'] / (state['em']['em_ns'] * 1e-9),
-                # B_em = M*(4+8+16) + C*(4+8) + T*40 algorithmic bytes per EM step
-                'em_bytes_per_step': int(sizes[1] * 28 + sizes[0] * 12 + n_tx * 40),
-                'em_algorithmic_GBps': (sizes[1] * 28 + sizes[0] * 12 + n_tx * 40)
-                                       * state['em']['iterations'] / max(state['em']['em_ns'], 1.0),
+                'em_bytes_per_step': em_bytes,
+                'em_algorithmic_GBps': em_bytes * state['em']['iterations'] / max(state['em']['em_ns'], 1.0),
                 'parallelism': 'reads sharded x%d, RCCL all-reduce f64[T] per EM step' % world,
+                'rccl_ranks': rccl_ranks,
                 'phase_ms': {'pack': pack_ns * 1e-6, 'map': map_ns * 1e-6, 'classes': class_ns * 1e-6,
                              'em': state['em']['em_ns'] * 1e-6},
             },
@@ -286,17 +452,28 @@ def main():
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic,
+                'traffic_source': traffic_source,
                 'algorithmic_bytes_per_launch': algorithmic,
                 # the probes are dependent random 16-B reads: the relevant ceiling is the chip's
                 # random-gather rate (52 G/s over a 2 GiB table, profiles/r01_gather_ceiling.log)
                 'l2_miss_rate_vs_random_gather_ceiling': (miss_rate / 52.3e9) if miss_rate else None,
-                'bytes_per_pair': algorithmic / n_units,
+                'bytes_per_unit': algorithmic / n_units,
                 'launch_ms': map_ns * 1e-6,
             },
         }
+        if em_steps_check:
+            line['config']['em_steps_over_ranks'] = em_steps_check
+        if bootstraps:
+            line['config']['bootstraps'] = bootstraps
+            line['config']['bootstraps_per_s'] = bootstraps * args.steps / state['boot_s']
+            line['config']['bootstrap_em_steps'] = state['boot_iters'] // args.steps
+            line['config']['phase_ms']['bootstraps'] = 1e3 * state['boot_s'] / args.steps
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(index, pool, tx_offsets, args.seed, args.read_len,
-                                                min(args.cpu_sample, n_units))
+            line['cpu_baseline'] = cpu_baseline(index, pool, tx_offsets, args.seed, read_len,
+                                                min(args.cpu_sample, n_units), paired,
+                                                bootstraps=min(bootstraps, 3))
+        if world == 1 and args.config == 1 and not args.no_e2e:
+            line['e2e'] = e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx)
         print(json.dumps(line), flush=True)
     if comm:
         _native.check(hip.skm_comm_destroy(comm))

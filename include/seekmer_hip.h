@@ -18,6 +18,7 @@
 #ifndef SEEKMER_HIP_H
 #define SEEKMER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -54,6 +55,11 @@ int skm_device_free(int device, void *ptr);
 int skm_device_upload(int device, void *dst, const void *src, int64_t bytes);
 int skm_device_download(int device, void *dst, const void *src, int64_t bytes);
 int skm_device_synchronize(int device);
+/* Page-locked host memory (hipHostMalloc).  A host batch that lives in it crosses PCIe by DMA
+ * at the full link rate; from pageable memory the runtime stages the copy.  Plain allocator
+ * signatures: skm_fastq_set_allocator takes this pair so that FASTQ slabs are page-locked. */
+void *skm_pinned_alloc(size_t bytes);
+void skm_pinned_free(void *ptr);
 /* Diagnostic: rate of random 16-byte gathers over a table of `table_bytes`
  * (power of two); chain=0 independent (throughput), chain=1 dependent
  * (latency under load).  The ceiling the index probes are priced against. */
@@ -105,6 +111,20 @@ int skm_mapper_destroy(skm_mapper *mapper);
  * seekmer/common.py:161-197).  Host buffers; copied to the GPU. */
 int skm_mapper_map_batch(skm_mapper *mapper, const char *bases,
                          const int64_t *offsets, int64_t n_units, int paired);
+/* The same without waiting for the kernels: the batch is copied to HBM on a staging stream
+ * by the calling thread (returns once the host arrays are free again) and queued; one worker
+ * per mapper maps the queued batches in submission order, so the copy of batch i+1 runs under
+ * the kernels of batch i -- the overlap the reference gets from parsing in one thread and
+ * mapping in others (seekmer/mapper.py:174-189).  Any thread may submit; integer results do
+ * not depend on the interleaving.  first_unit >= 0 gives the batch's place in the sample (the
+ * global index of its first unit): first-seen class order is then the -j1 order whatever the
+ * submission order; -1 = after the units mapped so far.  skm_mapper_sync waits for everything
+ * queued and returns the first failure; every call that reads or changes the table waits too.
+ * After a failed batch the handle holds a partial table until skm_mapper_reset / _clear. */
+int skm_mapper_map_batch_async(skm_mapper *mapper, const char *bases,
+                               const int64_t *offsets, int64_t n_units, int paired,
+                               int64_t first_unit);
+int skm_mapper_sync(skm_mapper *mapper);
 /* Same with the batch already resident in HBM (device pointers; max_read_len
  * must bound every read length). */
 int skm_mapper_map_batch_device(skm_mapper *mapper, const void *d_bases,
@@ -202,6 +222,7 @@ int skm_quant_timing(skm_quant *quant, double timing[4]);
 typedef struct skm_comm skm_comm;
 int skm_comm_unique_id(void *id128);                 /* rank 0: 128-byte id, single use */
 int skm_comm_create(int device, const void *id128, int rank, int world, skm_comm **out);
+int skm_comm_count(skm_comm *comm, int *count);     /* ncclCommCount: ranks RCCL itself sees */
 int skm_comm_destroy(skm_comm *comm);
 int skm_quant_set_comm(skm_quant *quant, skm_comm *comm);   /* NULL detaches */
 
@@ -232,6 +253,14 @@ int skm_built_free(skm_built *b);
 typedef struct skm_fastq skm_fastq;
 int skm_fastq_open(const char *const *paths, int n_paths, int paired,
                    int64_t batch_units, skm_fastq **out);
+/* Before the first skm_fastq_next.  set_allocator: where slabs live (default malloc/free; with
+ * skm_pinned_alloc/skm_pinned_free a batch crosses PCIe by DMA straight from its slab).
+ * set_parallel: n_threads > 0 asks for the parallel engine -- the files are memory-mapped, their
+ * newlines counted once, and whole batches are parsed side by side by n_threads workers and
+ * handed out in file order; same batches as the sequential engine.  It needs plain files whose
+ * line counts are multiples of four; *enabled = 0 (and the sequential engine stays) otherwise. */
+int skm_fastq_set_allocator(skm_fastq *reader, void *(*alloc)(size_t), void (*release)(void *));
+int skm_fastq_set_parallel(skm_fastq *reader, int n_threads, int *enabled);
 /* next batch: *n_units = 0 at end.  Buffers are owned by the reader and stay
  * valid until the next call.  names: '\n'-separated. */
 int skm_fastq_next(skm_fastq *reader, int64_t *n_units, const char **bases,
@@ -253,6 +282,12 @@ int skm_synth_free(void *p);
 int skm_synth_reads(uint64_t seed, const char *pool, const int64_t *tx_offsets,
                     int64_t n_tx, int64_t first_unit, int64_t n_units,
                     int read_len, int paired, int n_threads, char *bases);
+
+/* The same reads as FASTQ text (names r<ten digits>/<mate>, constant qualities), for measuring
+ * the path from files: bases = [n_units][mates][read_len] as skm_synth_reads fills it. */
+int skm_synth_fastq_write(const char *bases, int64_t n_units, int read_len, int paired,
+                          int64_t first_unit, const char *path1, const char *path2,
+                          int n_threads);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,8 @@ HIP_SYMBOLS = {
     'skm_device_synchronize': (ctypes.c_int, [ctypes.c_int]),
     'skm_device_gather_ceiling': (ctypes.c_int, [ctypes.c_int, c_i64, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, c_f64p]),
+    'skm_pinned_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
+    'skm_pinned_free': (None, [ctypes.c_void_p]),
     'skm_index_create': (ctypes.c_int, [ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_int, c_void_pp]),
@@ -48,6 +50,9 @@ HIP_SYMBOLS = {
     'skm_mapper_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_map_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64p, c_i64,
                                             ctypes.c_int]),
+    'skm_mapper_map_batch_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64p, c_i64,
+                                                  ctypes.c_int, c_i64]),
+    'skm_mapper_sync': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_map_batch_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, c_i64, ctypes.c_int,
                                                    ctypes.c_int32]),
@@ -78,6 +83,7 @@ HIP_SYMBOLS = {
     'skm_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_comm_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                        c_void_pp]),
+    'skm_comm_count': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     'skm_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_quant_set_comm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'skm_quant_infer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f64p, c_i64, ctypes.c_double,
@@ -92,6 +98,8 @@ HOST_SYMBOLS = {
     'skm_built_free': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_fastq_open': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
                                       c_i64, c_void_pp]),
+    'skm_fastq_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'skm_fastq_set_parallel': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'skm_fastq_next': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_void_pp, c_void_pp, c_void_pp,
                                       c_void_pp]),
     'skm_fastq_detach': (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
@@ -100,6 +108,8 @@ HOST_SYMBOLS = {
     'skm_synth_transcriptome': (ctypes.c_int, [ctypes.c_uint64, c_i64, c_i64p, c_void_pp,
                                                c_void_pp]),
     'skm_synth_free': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_synth_fastq_write': (ctypes.c_int, [ctypes.c_void_p, c_i64, ctypes.c_int, ctypes.c_int, c_i64,
+                                             ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]),
     'skm_synth_reads': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_void_p, c_i64p, c_i64, c_i64,
                                        c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p]),

@@ -248,9 +248,10 @@ class ReadBatch:
     to back) and `offsets` (int64[n_reads + 1]).  Unpacks like the reference's
     (count, names, reads) triple, so code written against the feeders works."""
 
-    __slots__ = ('count', 'bases', 'offsets', 'paired', '_names', '_name_offsets')
+    __slots__ = ('count', 'bases', 'offsets', 'paired', '_names', '_name_offsets', 'first_unit')
 
-    def __init__(self, count, bases, offsets, paired, names=None, name_offsets=None):
+    def __init__(self, count, bases, offsets, paired, names=None, name_offsets=None, first_unit=None):
+        self.first_unit = first_unit          # index of the batch's first unit in its sample, if known
         self.count = int(count)
         self.bases = bases
         self.offsets = offsets
@@ -295,13 +296,25 @@ class _FastqReader:
     """Owns one skm_fastq handle; closed when the feeder loop and every batch
     that borrowed a slab from it are gone."""
 
-    def __init__(self, names, paired, batch_units):
+    def __init__(self, names, paired, batch_units, threads=0, pinned=False):
         array = (ctypes.c_char_p * len(names))(*names)
         self.handle = ctypes.c_void_p()
         self.lock = threading.Lock()
-        _native.check_host(_native.host().skm_fastq_open(
+        self.parallel = False
+        host = _native.host()
+        _native.check_host(host.skm_fastq_open(
             array, len(names), int(paired), batch_units, ctypes.byref(self.handle)),
             'skm_fastq_open')
+        if pinned:          # slabs in page-locked memory: batches cross PCIe by DMA
+            hip = _native.hip()
+            _native.check_host(host.skm_fastq_set_allocator(
+                self.handle, ctypes.cast(hip.skm_pinned_alloc, ctypes.c_void_p),
+                ctypes.cast(hip.skm_pinned_free, ctypes.c_void_p)), 'skm_fastq_set_allocator')
+        if threads > 0:
+            enabled = ctypes.c_int(0)
+            _native.check_host(host.skm_fastq_set_parallel(self.handle, int(threads), ctypes.byref(enabled)),
+                               'skm_fastq_set_parallel')
+            self.parallel = bool(enabled.value)
 
     def recycle(self, slab):
         with self.lock:
@@ -341,15 +354,24 @@ class NativeReadFeeder:
     a batch are views of a slab owned by the reader; the slab goes back to the
     reader when the batch is dropped, so large batches do not pay for fresh
     pages again.  Compressed inputs are piped through zcat/bzcat/xzcat as the
-    reference does."""
+    reference does.
 
-    def __init__(self, paths, paired, batch_units=BUFFER_SIZE):
+    ``threads`` > 0 asks for the parallel engine (plain, uncompressed files whose line counts
+    are multiples of four: whole batches parsed side by side, handed out in file order; any
+    other input silently takes the sequential engine).  ``pinned`` puts the slabs in
+    page-locked memory (needs the GPU library).  Every batch carries ``first_unit``, its place
+    in the sample."""
+
+    def __init__(self, paths, paired, batch_units=BUFFER_SIZE, threads=0, pinned=False):
         paths = [pathlib.Path(p) for p in paths]
         if paired and len(paths) % 2 != 0:
             raise ValueError('cannot process odd numbers of pair-ended files')
         self.paths = paths
         self.paired = bool(paired)
         self.batch_units = int(batch_units)
+        self.threads = int(threads)
+        self.pinned = bool(pinned)
+        self.parallel = None                 # set when iteration starts
 
     def __iter__(self):
         tools = {'.gz': 'zcat', '.bz2': 'bzcat', '.xz': 'xzcat', '.lzma': 'xzcat'}
@@ -365,7 +387,10 @@ class NativeReadFeeder:
                     names.append(('/dev/fd/%d' % process.stdout.fileno()).encode())
                 else:
                     names.append(str(path).encode())
-            reader = _FastqReader(names, self.paired, self.batch_units)
+            threads = 0 if processes else self.threads          # (pipes are read sequentially)
+            reader = _FastqReader(names, self.paired, self.batch_units, threads, self.pinned)
+            self.parallel = reader.parallel
+            first_unit = 0
             n = ctypes.c_int64()
             p_bases, p_off = ctypes.c_void_p(), ctypes.c_void_p()
             p_names, p_noff = ctypes.c_void_p(), ctypes.c_void_p()
@@ -390,7 +415,9 @@ class NativeReadFeeder:
                 bases = view(p_bases, int(offsets[-1]) + 1, ctypes.c_uint8, numpy.uint8)
                 name_offsets = view(p_noff, n.value + 1, ctypes.c_int64, numpy.int64)
                 name_bytes = view(p_names, max(int(name_offsets[-1]), 1), ctypes.c_uint8, numpy.uint8)
-                batch = ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets)
+                batch = ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets,
+                                  first_unit=first_unit)
+                first_unit += n.value
                 yield batch
                 del batch, owner, bases, offsets, name_bytes, name_offsets, view
         finally:

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <numeric>
@@ -145,6 +147,31 @@ struct skm_mapper {
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
     double t_em_ns = 0, em_iters = 0;          // skm_quant_infer calls on this mapper
     unsigned long long stats_total[48] = {0};
+    // ---- host batches: staging lanes + one worker (skm_mapper_map_batch[_async])
+    // A host batch is copied to HBM on a lane's own stream by the thread that submits it (the
+    // copy of batch i+1 runs under the kernels of batch i) and then queued; the worker maps
+    // the queued batches in submission order on the mapper's stream, holding `mu` only for its
+    // batch.  Every call that reads or changes the table first waits for the queue to drain.
+    struct Lane {
+        DBuf<uint8_t> bases;
+        DBuf<int64_t> offsets;
+        hipStream_t stream = nullptr;
+        bool busy = false;
+    };
+    static constexpr int N_LANES = 3;
+    Lane lanes[N_LANES];
+    struct Job { int lane; int64_t n_units; int paired; int64_t offset_base; int64_t first_unit; uint64_t ticket; };
+    std::mutex q_mu;
+    std::condition_variable q_cv;             // job queued / stop
+    std::condition_variable done_cv;          // job finished, lane released
+    std::deque<Job> jobs;
+    std::thread worker;
+    bool worker_started = false, stop = false;
+    uint64_t next_ticket = 1, done_ticket = 0;
+    int job_error = SKM_OK;                   // first failure of a queued batch (sticky until reported)
+    uint64_t job_error_ticket = 0;
+    std::string job_error_msg;
+    DBuf<unsigned long long> scan_out;        // device-side max read length / monotonicity of a batch
     int vote[8] = {1, 1, 1, 1, 1, 1, 1, 0};   // quorum per action (start, lookup, merge, left, right, emit, scan)
 };
 
@@ -228,6 +255,21 @@ extern "C" int skm_device_synchronize(int device)
     SKM_TRY(set_device(device));
     HIP_TRY(hipDeviceSynchronize());
     return SKM_OK;
+}
+
+// Page-locked host memory: a batch handed over from it crosses the link at the full PCIe rate
+// and asynchronously (no staging copy by the runtime).  Plain C allocator signatures so that
+// libseekmer_host.so's FASTQ reader can take them as its slab allocator (skm_fastq_set_allocator).
+extern "C" void *skm_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void skm_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 // Diagnostic: random 16-byte gathers over a zero-filled table of `table_bytes`
@@ -570,9 +612,12 @@ int read_error(skm_mapper *m)
     return SKM_OK;
 }
 
+// first_unit: global index of the batch's first unit (first-seen values count from it), or -1
+// to continue after the units mapped so far
 int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_offsets,
-                       int64_t n_units, int paired, int max_len)
+                       int64_t n_units, int paired, int max_len, int64_t first_unit = -1)
 {
+    const int64_t unit_base = first_unit >= 0 ? first_unit : m->units_done;
     skm_index *ix = m->ix;
     const int64_t n_reads = paired ? 2 * n_units : n_units;
     const int words = (max_len + 31) / 32 + 1;
@@ -675,7 +720,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         // insert -> prefix sum over the creators -> commit -> totals -> verify: one pipeline,
         // one synchronisation; the optimistic case needs a single pass
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
-        launch_class_insert(m->t, b, m->units_done, m->unit_slot.p, m->unit_claim.p, pass > 0, m->stream);
+        launch_class_insert(m->t, b, unit_base, m->unit_slot.p, m->unit_claim.p, pass > 0, m->stream);
         if (device_exclusive_scan_u64(m->unit_claim.p, m->claim_scan.p, n_units, m->counters.p + CTR_CREATED,
                                       m->scan_temp.p, scan_bytes, m->stream))
             return fail(SKM_ERR_HIP, "prefix sum over the new classes failed: %s", hipGetErrorString(hipGetLastError()));
@@ -705,7 +750,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     if ((uint64_t)m->host_classes * 2 > m->t.slot_mask + 1)
         SKM_TRY(table_grow(m, (m->t.slot_mask + 1) * 2, 0));
     m->units_done += n_units;
-    m->first_seen_bound = std::max(m->first_seen_bound, m->units_done);
+    m->first_seen_bound = std::max(m->first_seen_bound, std::max(m->units_done, unit_base + n_units));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->t_pack_ns += ms * 1e6;
     HIP_TRY(hipEventElapsedTime(&ms, m->ev[1], m->ev[2])); m->t_map_ns += ms * 1e6;
@@ -740,7 +785,18 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
 {
     if (!m) return SKM_OK;
     (void)hipSetDevice(m->ix->device);
+    if (m->worker_started) {
+        { std::lock_guard<std::mutex> hold(m->q_mu); m->stop = true; }
+        m->q_cv.notify_all();
+        m->worker.join();                     // (finishes what is queued)
+    }
     (void)hipStreamSynchronize(m->stream);
+    for (auto &lane : m->lanes) {
+        if (lane.stream) { (void)hipStreamSynchronize(lane.stream); (void)hipStreamDestroy(lane.stream); }
+        lane.bases.release();
+        lane.offsets.release();
+    }
+    m->scan_out.release();
     m->slots.release(); m->arena.release(); m->class_list.release();
     m->counters.release();
     m->error.release(); m->bases.release(); m->offsets.release(); m->records.release();
@@ -755,36 +811,153 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     return SKM_OK;
 }
 
-extern "C" int skm_mapper_map_batch(skm_mapper *m, const char *bases, const int64_t *offsets,
-                                    int64_t n_units, int paired)
+namespace {
+
+// ---- host batches: staging lanes and the mapping worker --------------------------------
+int run_job(skm_mapper *m, const skm_mapper::Job &job)
+{
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    skm_mapper::Lane &lane = m->lanes[job.lane];
+    const int64_t n_reads = job.paired ? 2 * job.n_units : job.n_units;
+    // longest read and monotonicity from the offsets in HBM (the lane's copy is complete)
+    SKM_TRY(m->scan_out.ensure(2));
+    HIP_TRY(hipMemsetAsync(m->scan_out.p, 0, 16, m->stream));
+    launch_offsets_scan(lane.offsets.p, n_reads, job.offset_base, m->scan_out.p, m->stream);   // (and rebases them to 0)
+    HIP_TRY(hipGetLastError());
+    unsigned long long *scan = m->pinned + 40;
+    HIP_TRY(hipMemcpyAsync(scan, m->scan_out.p, 16, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (scan[1]) return fail(SKM_ERR_ARG, "offsets are not monotone (%llu descents)", scan[1]);
+    if (scan[0] > (1ULL << 20)) return fail(SKM_ERR_ARG, "read longer than 2^20 bases");
+    return map_batch_resident(m, lane.bases.p, lane.offsets.p, job.n_units, job.paired, (int)scan[0],
+                              job.first_unit);
+}
+
+void worker_main(skm_mapper *m)
+{
+    for (;;) {
+        skm_mapper::Job job;
+        {
+            std::unique_lock<std::mutex> hold(m->q_mu);
+            m->q_cv.wait(hold, [&] { return m->stop || !m->jobs.empty(); });
+            if (m->jobs.empty()) return;          // stop requested and nothing left
+            job = m->jobs.front();
+            m->jobs.pop_front();
+        }
+        int rc = SKM_OK;
+        std::string message;
+        bool skip;
+        {
+            std::lock_guard<std::mutex> hold(m->q_mu);
+            skip = m->job_error != SKM_OK;        // after a failure the table is not to be trusted
+        }
+        if (!skip) {
+            rc = run_job(m, job);
+            if (rc != SKM_OK) message = g_error;  // (this thread's message)
+        }
+        {
+            std::lock_guard<std::mutex> hold(m->q_mu);
+            if (rc != SKM_OK && m->job_error == SKM_OK) {
+                m->job_error = rc;
+                m->job_error_ticket = job.ticket;
+                m->job_error_msg = message;
+            }
+            m->lanes[job.lane].busy = false;
+            m->done_ticket = job.ticket;
+        }
+        m->done_cv.notify_all();
+    }
+}
+
+// wait until every queued batch up to `ticket` (0 = all) has been mapped; reports (and, with
+// `consume`, forgets) the first failure among them
+int wait_jobs(skm_mapper *m, uint64_t ticket, bool consume)
+{
+    std::unique_lock<std::mutex> hold(m->q_mu);
+    const uint64_t upto = ticket ? ticket : m->next_ticket - 1;
+    m->done_cv.wait(hold, [&] { return m->done_ticket >= upto; });
+    if (m->job_error != SKM_OK && m->job_error_ticket <= upto) {
+        const int rc = m->job_error;
+        const std::string message = m->job_error_msg;
+        if (consume) { m->job_error = SKM_OK; m->job_error_ticket = 0; m->job_error_msg.clear(); }
+        g_error = message;
+        return rc;
+    }
+    return SKM_OK;
+}
+
+int submit_batch(skm_mapper *m, const char *bases, const int64_t *offsets, int64_t n_units, int paired,
+                 int64_t first_unit, uint64_t *ticket_out)
 {
     if (!m || !offsets || n_units < 0) return fail(SKM_ERR_ARG, "bad argument");
     if (n_units > 0 && !bases) return fail(SKM_ERR_ARG, "bases is NULL");
-    std::lock_guard<std::mutex> lock(m->mu);
+    if (n_units >= (1LL << 31)) return fail(SKM_ERR_ARG, "more than 2^31 - 1 units in one batch");
     SKM_TRY(set_device(m->ix->device));
     const int64_t n_reads = paired ? 2 * n_units : n_units;
-    int64_t max_len = 0;
-    for (int64_t r = 0; r < n_reads; ++r) {
-        const int64_t len = offsets[r + 1] - offsets[r];
-        if (len < 0) return fail(SKM_ERR_ARG, "offsets are not monotone at read %lld", (long long)r);
-        max_len = std::max(max_len, len);
-    }
-    if (max_len > (1 << 20)) return fail(SKM_ERR_ARG, "read longer than 2^20 bases");
     const int64_t n_bytes = offsets[n_reads] - offsets[0];
-    SKM_TRY(m->bases.ensure((size_t)n_bytes + 64));
-    SKM_TRY(m->offsets.ensure((size_t)n_reads + 1));
-    std::vector<int64_t> rel;
-    const int64_t *src_off = offsets;
-    if (offsets[0] != 0) {
-        rel.resize(n_reads + 1);
-        for (int64_t r = 0; r <= n_reads; ++r) rel[r] = offsets[r] - offsets[0];
-        src_off = rel.data();
+    if (n_bytes < 0) return fail(SKM_ERR_ARG, "offsets are not monotone");
+    // a free lane (at most N_LANES batches are in HBM at a time: one being mapped, others copied)
+    int li = -1;
+    {
+        std::unique_lock<std::mutex> hold(m->q_mu);
+        if (!m->worker_started) {
+            m->worker = std::thread(worker_main, m);
+            m->worker_started = true;
+        }
+        m->done_cv.wait(hold, [&] {
+            for (int i = 0; i < skm_mapper::N_LANES; ++i) if (!m->lanes[i].busy) { li = i; return true; }
+            return false;
+        });
+        m->lanes[li].busy = true;
     }
+    skm_mapper::Lane &lane = m->lanes[li];
+    auto release = on_exit([&]() {
+        { std::lock_guard<std::mutex> hold(m->q_mu); lane.busy = false; }
+        m->done_cv.notify_all();
+    });
+    if (!lane.stream) HIP_TRY(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+    SKM_TRY(lane.bases.ensure((size_t)n_bytes + 64));
+    SKM_TRY(lane.offsets.ensure((size_t)n_reads + 1));
+    // pinned sources go over the link at full rate and asynchronously; pageable ones are staged
+    // by the runtime.  Either way the source is free again when this call returns.
     if (n_bytes)
-        HIP_TRY(hipMemcpyAsync(m->bases.p, bases + offsets[0], (size_t)n_bytes, hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipMemcpyAsync(m->offsets.p, src_off, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return map_batch_resident(m, m->bases.p, m->offsets.p, n_units, paired, (int)max_len);
+        HIP_TRY(hipMemcpyAsync(lane.bases.p, bases + offsets[0], (size_t)n_bytes, hipMemcpyHostToDevice, lane.stream));
+    HIP_TRY(hipMemcpyAsync(lane.offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                           lane.stream));
+    HIP_TRY(hipStreamSynchronize(lane.stream));
+    uint64_t ticket;
+    {
+        std::lock_guard<std::mutex> hold(m->q_mu);
+        ticket = m->next_ticket++;
+        m->jobs.push_back(skm_mapper::Job{li, n_units, paired, offsets[0], first_unit, ticket});
+    }
+    release.dismiss();
+    m->q_cv.notify_one();
+    if (ticket_out) *ticket_out = ticket;
+    return SKM_OK;
+}
+
+}  // namespace
+
+extern "C" int skm_mapper_map_batch_async(skm_mapper *m, const char *bases, const int64_t *offsets,
+                                          int64_t n_units, int paired, int64_t first_unit)
+{
+    return submit_batch(m, bases, offsets, n_units, paired, first_unit, nullptr);
+}
+
+extern "C" int skm_mapper_sync(skm_mapper *m)
+{
+    if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    return wait_jobs(m, 0, true);
+}
+
+extern "C" int skm_mapper_map_batch(skm_mapper *m, const char *bases, const int64_t *offsets,
+                                    int64_t n_units, int paired)
+{
+    uint64_t ticket = 0;
+    SKM_TRY(submit_batch(m, bases, offsets, n_units, paired, -1, &ticket));
+    return wait_jobs(m, ticket, true);
 }
 
 extern "C" int skm_mapper_map_batch_device(skm_mapper *m, const void *d_bases, const void *d_offsets,
@@ -792,6 +965,7 @@ extern "C" int skm_mapper_map_batch_device(skm_mapper *m, const void *d_bases, c
 {
     if (!m || !d_offsets || n_units < 0 || max_read_len < 0)
         return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     return map_batch_resident(m, (const uint8_t *)d_bases, (const int64_t *)d_offsets, n_units,
@@ -803,6 +977,7 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
                                      int32_t *entries, int64_t cap_entries, int64_t *n_entries)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     const int64_t n = m->last_units;
@@ -859,6 +1034,7 @@ extern "C" int skm_mapper_last_batch(skm_mapper *m, int32_t *begin, int32_t *end
 extern "C" int skm_mapper_keep_spans(skm_mapper *m, int enable)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    (void)wait_jobs(m, 0, false);
     std::lock_guard<std::mutex> lock(m->mu);
     m->keep_spans = enable != 0;
     return SKM_OK;
@@ -867,6 +1043,7 @@ extern "C" int skm_mapper_keep_spans(skm_mapper *m, int enable)
 extern "C" int skm_mapper_summary(skm_mapper *m, int64_t summary[4])
 {
     if (!m || !summary) return fail(SKM_ERR_ARG, "NULL argument");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     unsigned long long ctr[4];
@@ -882,6 +1059,7 @@ extern "C" int skm_mapper_export(skm_mapper *m, int64_t *class_offsets, int32_t 
                                  int64_t *class_counts, int64_t *first_seen, int64_t *fld)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     if (fld)
@@ -929,6 +1107,7 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
     if (!m || n_classes < 0 || unaligned < 0) return fail(SKM_ERR_ARG, "bad argument");
     if (n_classes && (!class_offsets || !class_targets || !class_counts || !first_seen))
         return fail(SKM_ERR_ARG, "NULL class arrays");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     std::vector<unsigned long long> add(CTR_WORDS, 0);
@@ -978,6 +1157,7 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
 extern "C" int skm_mapper_clear(skm_mapper *m)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    (void)wait_jobs(m, 0, true);            // (a failed queued batch is forgotten with the table)
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     // MapResult.clear only clears the counter (mapper.py:143-145): the FLD stays
@@ -992,6 +1172,7 @@ extern "C" int skm_mapper_clear(skm_mapper *m)
 extern "C" int skm_mapper_reset(skm_mapper *m)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    (void)wait_jobs(m, 0, true);            // (a failed queued batch is forgotten with the table)
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     SKM_TRY(table_reset(m, m->t.slot_mask + 1));
@@ -1004,6 +1185,7 @@ extern "C" int skm_mapper_reset(skm_mapper *m)
 extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
 {
     if (!m || !stats) return fail(SKM_ERR_ARG, "NULL argument");
+    (void)wait_jobs(m, 0, false);
     std::lock_guard<std::mutex> lock(m->mu);
     stats[0] = m->t_pack_ns; stats[1] = m->t_map_ns; stats[2] = m->t_class_ns;
     stats[3] = m->batches; stats[4] = (double)m->units_done;
@@ -1017,6 +1199,7 @@ extern "C" int skm_mapper_timing(skm_mapper *m, double stats[8])
 extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[48])
 {
     if (!m || !out) return fail(SKM_ERR_ARG, "NULL argument");
+    (void)wait_jobs(m, 0, false);
     std::lock_guard<std::mutex> lock(m->mu);
     for (int i = 0; i < 48; ++i) out[i] = (int64_t)m->stats_total[i];
     return SKM_OK;
@@ -1025,6 +1208,7 @@ extern "C" int skm_mapper_access_stats(skm_mapper *m, int64_t out[48])
 extern "C" int skm_mapper_set_stats(skm_mapper *m, int enable)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
+    (void)wait_jobs(m, 0, false);
     std::lock_guard<std::mutex> lock(m->mu);
     m->want_stats = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     for (auto &v : m->stats_total) v = 0;
@@ -1125,6 +1309,7 @@ struct Rccl {
     int (*GetUniqueId)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 struct UniqueId { char internal[128]; };
@@ -1143,6 +1328,7 @@ int load_rccl()
     g_comm_init = (comm_init_fn)dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    g_rccl.CommCount = (int (*)(void *, int *))dlsym(lib, "ncclCommCount");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_comm_init || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(SKM_ERR_COMM, "librccl.so lacks a required symbol");
@@ -1331,6 +1517,7 @@ extern "C" int skm_quant_create(int device, int64_t n_tx, int64_t n_classes,
 extern "C" int skm_quant_create_from_mapper(skm_mapper *m, int64_t n_tx, skm_quant **out)
 {
     if (!m || !out || n_tx <= 0) return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     const int64_t C = m->host_classes, M = m->host_arena_used;
@@ -1355,6 +1542,7 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
                                double *tpm, double *effective_lengths, int64_t *iters)
 {
     if (!m || !lengths || n_tx <= 0) return fail(SKM_ERR_ARG, "bad argument");
+    SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
     if (comm && comm->device != m->ix->device)
         return fail(SKM_ERR_ARG, "communicator and mapper live on different GPUs");
@@ -1591,6 +1779,14 @@ extern "C" int skm_comm_create(int device, const void *id128, int rank, int worl
                     g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     }
     *out = c;
+    return SKM_OK;
+}
+
+extern "C" int skm_comm_count(skm_comm *c, int *count)
+{
+    if (!c || !count) return fail(SKM_ERR_ARG, "NULL argument");
+    if (!g_rccl.CommCount) return fail(SKM_ERR_COMM, "librccl.so lacks ncclCommCount");
+    NCCL_TRY(g_rccl.CommCount(c->comm, count));
     return SKM_OK;
 }
 

@@ -66,6 +66,35 @@ __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned lo
     return ~0ULL;
 }
 
+// probe_claim continued from a slot whose (key, first_seen) pair has been read already
+__device__ __forceinline__ uint64_t probe_claim_from(const ClassTable &t, unsigned long long key,
+                                                     ulonglong2 head, bool &claimed, uint64_t limit,
+                                                     unsigned long long &seen)
+{
+    uint64_t slot = key & t.slot_mask;
+    claimed = false;
+    if (limit > t.slot_mask + 1) limit = t.slot_mask + 1;
+    for (uint64_t n = 0; n < limit; ++n) {
+        if (n) head = *reinterpret_cast<const ulonglong2 *>(&t.slots[slot]);
+        unsigned long long cur = head.x;
+        seen = head.y;
+        if (cur == 0) {
+            cur = atomicCAS(&t.slots[slot].key, 0ULL, key);
+            if (cur == 0) { claimed = true; return slot; }
+        }
+        if (cur == key) return slot;
+        slot = (slot + 1) & t.slot_mask;
+    }
+    return ~0ULL;
+}
+
+// Records are taken INSERT_WIDTH at a time per lane: their keys, then the home slots of all of
+// them, are fetched before any is looked at -- the chain key -> slot -> atomic of one record
+// runs under the chains of the others (one record per iteration left the kernel waiting on a
+// single dependent miss per lane; the atomics themselves run at the fabric's ~20 G/s for
+// scattered addresses).
+constexpr int INSERT_WIDTH = 4;
+
 __global__ void __launch_bounds__(256)
 class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot,
                     unsigned long long *unit_claim, bool retry_deferred)
@@ -75,43 +104,56 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     __shared__ unsigned int s_unaligned;
     if (threadIdx.x == 0) s_unaligned = 0;
     __syncthreads();
+    unsigned int unaligned = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // (u walks the batch's RECORDS, skm_kernels.h: MapBatch; unit_slot / unit_claim are by record)
-    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
-         u += (int64_t)gridDim.x * blockDim.x) {
-        // every unit leaves with ONE store to unit_slot (new units) and ONE to unit_claim, issued
-        // at the end: on gfx9 a store issued before the loads would have to drain in front of them
-        unsigned long long claim = 0;
-        int64_t where = -1;
-        bool touched = true;
-        if (retry_deferred && unit_slot[u] != -2) {
-            touched = false;                  // counted in an earlier pass: only its claim is cleared
-        } else {
-            const unsigned long long key = b.rec_key[u];
-            if (key == 0) {                   // empty tuple = unaligned, mapper.py:87
-                const unsigned long long peers = __ballot(1);
-                if ((int)(threadIdx.x & 63) == __builtin_ctzll(peers))
-                    atomicAdd(&s_unaligned, (unsigned int)__popcll(peers));
-            } else {
-                bool claimed;
-                unsigned long long seen = ~0ULL;
-                const uint64_t slot = probe_claim(t, key, claimed, CLASS_PROBE_LIMIT, &seen);
-                if (slot == ~0ULL) {          // deferred: counted after the table has grown
-                    atomicAdd(t.n_deferred, 1ULL);
-                    where = -2;
-                } else {
-                    // the creator of a class stores its tuple later (class_commit_kernel): one
-                    // class (bits 40+) and n arena ids (bits 0-39), placed by a device-wide scan
-                    if (claimed) claim = (1ULL << 40) | (b.rec_tuple[u] >> 40);
-                    atomicAdd(&t.slots[slot].count, 1ULL);
-                    const unsigned long long unit = (unsigned long long)(unit_base + b.rec_unit[u]);
-                    if (claimed || seen > unit) atomicMin(&t.slots[slot].first_seen, unit);
-                    where = (int64_t)slot;
-                }
-            }
+    for (int64_t u0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u0 < b.n_units; u0 += INSERT_WIDTH * stride) {
+        unsigned long long key[INSERT_WIDTH];
+        ulonglong2 head[INSERT_WIDTH];
+        bool live[INSERT_WIDTH];
+#pragma unroll
+        for (int k = 0; k < INSERT_WIDTH; ++k) {
+            const int64_t u = u0 + k * stride;
+            live[k] = u < b.n_units && !(retry_deferred && unit_slot[u] != -2);
+            key[k] = live[k] ? b.rec_key[u] : 0;
         }
-        if (touched) unit_slot[u] = where;
-        unit_claim[u] = claim;
+#pragma unroll
+        for (int k = 0; k < INSERT_WIDTH; ++k)
+            head[k] = *reinterpret_cast<const ulonglong2 *>(&t.slots[key[k] & t.slot_mask]);   // (key 0: slot 0, unused)
+#pragma unroll
+        for (int k = 0; k < INSERT_WIDTH; ++k) {
+            const int64_t u = u0 + k * stride;
+            if (u >= b.n_units) continue;
+            // every record leaves with ONE store to unit_slot (new ones) and ONE to unit_claim, issued
+            // at the end: on gfx9 a store issued before the loads would have to drain in front of them
+            unsigned long long claim = 0;
+            int64_t where = -1;
+            if (live[k]) {
+                if (key[k] == 0) {                // empty tuple = unaligned, mapper.py:87
+                    ++unaligned;
+                } else {
+                    bool claimed;
+                    unsigned long long seen = ~0ULL;
+                    const uint64_t slot = probe_claim_from(t, key[k], head[k], claimed, CLASS_PROBE_LIMIT, seen);
+                    if (slot == ~0ULL) {          // deferred: counted after the table has grown
+                        atomicAdd(t.n_deferred, 1ULL);
+                        where = -2;
+                    } else {
+                        // the creator of a class stores its tuple later (class_commit_kernel): one
+                        // class (bits 40+) and n arena ids (bits 0-39), placed by a device-wide scan
+                        if (claimed) claim = (1ULL << 40) | (b.rec_tuple[u] >> 40);
+                        atomicAdd(&t.slots[slot].count, 1ULL);
+                        const unsigned long long unit = (unsigned long long)(unit_base + b.rec_unit[u]);
+                        if (claimed || seen > unit) atomicMin(&t.slots[slot].first_seen, unit);
+                        where = (int64_t)slot;
+                    }
+                }
+                unit_slot[u] = where;
+            }
+            unit_claim[u] = claim;                // (a record counted in an earlier pass: only its claim is cleared)
+        }
     }
+    if (unaligned) atomicAdd(&s_unaligned, unaligned);
     __syncthreads();
     if (threadIdx.x == 0 && s_unaligned) atomicAdd(t.n_unaligned, (unsigned long long)s_unaligned);
     if (!retry_deferred && blockIdx.x == 0 && threadIdx.x == 0)
@@ -164,21 +206,37 @@ class_totals_kernel(ClassTable t, MapBatch b, const unsigned long long *created,
 __global__ void __launch_bounds__(256)
 class_verify_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot)
 {
-    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
-         u += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t slot = unit_slot[u];
-        if (slot < 0) continue;
-        const unsigned long long mine_at = b.rec_tuple[u];
-        const int n = (int)(mine_at >> 40);
-        const long long stored = t.slots[slot].tuple;
-        bool same = stored >= 0 && tuple_len(stored) == n;
-        if (same) {
-            const int32_t *mine = b.unit_entries + (mine_at & ((1ULL << 40) - 1));
-            const int32_t *ref = t.arena + tuple_offset(stored);
-            for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
+    // (four records per lane at a time: their slots' tuple words, then the first ids of both
+    // sides, are in flight together)
+    constexpr int WIDTH = 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool all_same = true;
+    for (int64_t u0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u0 < b.n_units; u0 += WIDTH * stride) {
+        int64_t slot[WIDTH];
+        unsigned long long mine_at[WIDTH];
+        long long stored[WIDTH];
+#pragma unroll
+        for (int k = 0; k < WIDTH; ++k) {
+            const int64_t u = u0 + k * stride;
+            slot[k] = u < b.n_units ? unit_slot[u] : -1;
+            mine_at[k] = u < b.n_units ? b.rec_tuple[u] : 0;
         }
-        if (!same) atomicExch(t.error, SKM_ERR_COLLISION);
+#pragma unroll
+        for (int k = 0; k < WIDTH; ++k) stored[k] = slot[k] >= 0 ? t.slots[slot[k]].tuple : 0;
+#pragma unroll
+        for (int k = 0; k < WIDTH; ++k) {
+            if (slot[k] < 0) continue;
+            const int n = (int)(mine_at[k] >> 40);
+            bool same = stored[k] >= 0 && tuple_len(stored[k]) == n;
+            if (same) {
+                const int32_t *mine = b.unit_entries + (mine_at[k] & ((1ULL << 40) - 1));
+                const int32_t *ref = t.arena + tuple_offset(stored[k]);
+                for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
+            }
+            all_same &= same;
+        }
     }
+    if (!all_same) atomicExch(t.error, SKM_ERR_COLLISION);
 }
 
 // move every occupied slot of `from` into the (larger, initialised) table `to`

@@ -223,8 +223,14 @@ __global__ void __launch_bounds__(256)
 effective_lengths_kernel(const unsigned long long *__restrict__ fld,
                          const double *__restrict__ lengths, int64_t n_tx, double *__restrict__ out)
 {
+    // Only the bins with p_i != 0 are visited: a term max(len - i, 1) * 0.0 is +0.0 and adding
+    // +0.0 leaves the running sum as it is, bit for bit (the sum starts at +0.0 and every term
+    // is >= 0); a NaN bin (empty histogram: 0 / 0) is not zero and stays in.  A fragment-length
+    // histogram has a few hundred occupied bins out of 2000.
     __shared__ double p[MAX_FRAGMENT_LENGTH];
+    __shared__ int bin[MAX_FRAGMENT_LENGTH];
     __shared__ unsigned long long total_s;
+    __shared__ int n_bins;
     if (threadIdx.x == 0) {
         unsigned long long total = 0;
         for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) total += fld[i];
@@ -232,17 +238,24 @@ effective_lengths_kernel(const unsigned long long *__restrict__ fld,
     }
     __syncthreads();
     const double total = (double)(long long)total_s;
-    for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x)
-        p[i] = (double)(long long)fld[i] / total;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) {
+            const double v = (double)(long long)fld[i] / total;
+            if (!(v == 0.0)) { p[n] = v; bin[n] = i; ++n; }
+        }
+        n_bins = n;
+    }
     __syncthreads();
+    const int n = n_bins;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_tx;
          t += (int64_t)gridDim.x * blockDim.x) {
         const double len = lengths[t];
         double acc = 0.0;
-        for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) {
-            double v = len - (double)i;
+        for (int k = 0; k < n; ++k) {
+            double v = len - (double)bin[k];
             if (v < 1.0) v = 1.0;
-            acc += v * p[i];
+            acc += v * p[k];
         }
         out[t] = acc;
     }
@@ -439,14 +452,44 @@ __device__ __attribute__((noinline)) double np_combine(int n, const double *leaf
 template <>
 __device__ __attribute__((noinline)) double np_combine<0>(int, const double *, int *) { return 0.0; }
 
-__global__ void __launch_bounds__(256)
+// A full block of 8192 elements splits evenly all the way down: 64 leaves of 128 elements,
+// combined as a balanced binary tree.  Eight lanes per leaf run numpy's eight strided
+// accumulators (lane j adds elements j, j + 8, ... of the leaf in order), the combination
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is a three-step butterfly over those lanes and the 64 leaf
+// sums meet in a six-step butterfly -- the same additions in the same association (a + b = b + a
+// exactly, so only the shape of the tree matters), with none of the recursion of the general path.
+__device__ __forceinline__ void np_sum_full_block(const double *__restrict__ a, double *__restrict__ out)
+{
+    __shared__ double leaf[64];
+    const int l = threadIdx.x >> 3, j = threadIdx.x & 7;          // 512 lanes: leaf, accumulator
+    const double *p = a + l * 128 + j;
+    double r = p[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r += p[8 * i];
+    r += __shfl_xor(r, 1, 8);
+    r += __shfl_xor(r, 2, 8);
+    r += __shfl_xor(r, 4, 8);
+    if (j == 0) leaf[l] = r;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double s = leaf[threadIdx.x];
+        for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d, 64);
+        if (threadIdx.x == 0) *out = s;
+    }
+}
+
+__global__ void __launch_bounds__(512)
 np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ block_sums)
 {
+    const int64_t first = blockIdx.x * (int64_t)8192;
+    const int len = (int)min((int64_t)8192, n - first);
+    if (len == 8192) {                      // (block-uniform)
+        np_sum_full_block(a + first, block_sums + blockIdx.x);
+        return;
+    }
     __shared__ double staged[8192];          // the block, fetched coalesced; leaves then read LDS
     __shared__ int leaf_lo[NP_MAX_LEAVES], leaf_n[NP_MAX_LEAVES], n_leaves;
     __shared__ double leaf_sum[NP_MAX_LEAVES];
-    const int64_t first = blockIdx.x * (int64_t)8192;
-    const int len = (int)min((int64_t)8192, n - first);
     for (int i = threadIdx.x; i < len; i += blockDim.x) staged[i] = a[first + i];
     if (threadIdx.x == 0) {
         int count = 0;
@@ -506,7 +549,7 @@ void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sum
 {
     const int64_t n_blocks = (n + 8191) / 8192;
     if (n_blocks)
-        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream,
+        hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks), dim3(512), 0, stream,
                            a, n, block_sums);
     hipLaunchKernelGGL(np_sum_final_kernel, dim3(1), dim3(1), 0, stream, block_sums, n_blocks, divisor, out);
 }

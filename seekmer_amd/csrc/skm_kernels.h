@@ -49,6 +49,9 @@ constexpr int MAP_CONTEXTS = 480;     // unit contexts per block: 16 words + 7 r
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
+// out[0] = longest read, out[1] = places where the offsets step backwards; then offsets -= base
+void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,
+                         hipStream_t stream);
 void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream);
 // build the bucket table from the reference table and check the reference probe (see DevBucket);
 // report: [0] placed [1] placed outside the home bucket [2] k-mers met twice [3] slots the

@@ -119,6 +119,36 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
     }
 }
 
+// A host batch's offsets as they arrived in HBM: rebase to the first byte copied, find the
+// longest read and count the places where the offsets step backwards (out[0] = max length,
+// out[1] = descents) -- the host then never walks the n_reads + 1 offsets itself.
+__global__ void __launch_bounds__(256)
+offsets_scan_kernel(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out)
+{
+    long long longest = 0;
+    unsigned long long descents = 0;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_reads;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const long long len = offsets[r + 1] - offsets[r];
+        if (len < 0) ++descents;
+        longest = max(longest, len);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        longest = max(longest, __shfl_xor(longest, d, 64));
+        descents += __shfl_xor(descents, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out[0], (unsigned long long)longest);
+        if (descents) atomicAdd(&out[1], descents);
+    }
+}
+__global__ void __launch_bounds__(256)
+offsets_rebase_kernel(int64_t *offsets, int64_t n, int64_t base)
+{
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n;
+         r += (int64_t)gridDim.x * blockDim.x) offsets[r] -= base;
+}
+
 // reference contig rows (48 B) -> DevContig (32 B)
 __global__ void __launch_bounds__(256)
 pack_contigs_kernel(const ContigEntry *__restrict__ in, int64_t n, DevContig *__restrict__ out)
@@ -1285,6 +1315,18 @@ void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *bucket
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(4096), dim3(256), 0, stream, ix.kmers, n_slots, buckets,
                        bucket_mask, bucket_shift, report);
     hipLaunchKernelGGL(probe_check_kernel, dim3(4096), dim3(256), 0, stream, ix, n_slots, report);
+}
+
+void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,
+                         hipStream_t stream)
+{
+    if (n_reads <= 0) return;
+    int64_t blocks = (n_reads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(offsets_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offsets, n_reads, base, out);
+    if (base != 0)
+        hipLaunchKernelGGL(offsets_rebase_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offsets,
+                           n_reads + 1, base);
 }
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,

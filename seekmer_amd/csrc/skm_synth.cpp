@@ -8,6 +8,9 @@
 // threads and is reproducible bit for bit.
 #include "../../include/seekmer_hip.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -172,4 +175,58 @@ extern "C" int skm_synth_reads(uint64_t seed, const char *pool, const int64_t *t
         for (auto &th : pool_threads) th.join();
     }
     return SKM_OK;
+}
+
+// Reads as FASTQ text, for measuring the path from files: unit u of the fixed-length batch
+// `bases` ([n_units][mates][read_len], the layout skm_synth_reads fills) becomes the record
+// "@r<first_unit + u, ten digits>/<mate>\n<bases>\n+\n<read_len x 'I'>\n" of path1 (mate 1) and
+// path2 (mate 2, paired only).  Every record has the same size, so threads write disjoint ranges.
+extern "C" int skm_synth_fastq_write(const char *bases, int64_t n_units, int read_len, int paired,
+                                     int64_t first_unit, const char *path1, const char *path2,
+                                     int n_threads)
+{
+    if (!bases || n_units < 0 || read_len < 1 || !path1 || (paired && !path2)) return SKM_ERR_ARG;
+    const int mates = paired ? 2 : 1;
+    const size_t record = (size_t)(2 * read_len + 19);
+    int fds[2] = {-1, -1};
+    for (int m = 0; m < mates; ++m) {
+        fds[m] = open(m ? path2 : path1, O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (fds[m] < 0 || ftruncate(fds[m], (off_t)(record * (size_t)n_units)) != 0) {
+            for (int k = 0; k <= m; ++k) if (fds[k] >= 0) close(fds[k]);
+            return SKM_ERR_IO;
+        }
+    }
+    bool failed = false;
+    auto work = [&](int64_t lo, int64_t hi) {
+        constexpr int64_t CHUNK = 8192;
+        std::vector<char> buf((size_t)CHUNK * record);
+        for (int m = 0; m < mates; ++m) {
+            for (int64_t first = lo; first < hi; first += CHUNK) {
+                const int64_t last = std::min(hi, first + CHUNK);
+                char *p = buf.data();
+                for (int64_t u = first; u < last; ++u) {
+                    int64_t id = first_unit + u;
+                    p[0] = '@'; p[1] = 'r';
+                    for (int d = 11; d >= 2; --d) { p[d] = (char)('0' + id % 10); id /= 10; }
+                    p[12] = '/'; p[13] = (char)('1' + m); p[14] = '\n';
+                    memcpy(p + 15, bases + ((size_t)u * mates + m) * read_len, (size_t)read_len);
+                    p[15 + read_len] = '\n'; p[16 + read_len] = '+'; p[17 + read_len] = '\n';
+                    memset(p + 18 + read_len, 'I', (size_t)read_len);
+                    p[18 + 2 * read_len] = '\n';
+                    p += record;
+                }
+                const size_t bytes = (size_t)(last - first) * record;
+                if (pwrite(fds[m], buf.data(), bytes, (off_t)((size_t)first * record)) != (ssize_t)bytes)
+                    failed = true;
+            }
+        }
+    };
+    if (n_threads < 1) n_threads = 1;
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, n_units / 8192));
+    std::vector<std::thread> pool_threads;
+    for (int i = 0; i < n_threads; ++i)
+        pool_threads.emplace_back(work, n_units * i / n_threads, n_units * (i + 1) / n_threads);
+    for (auto &th : pool_threads) th.join();
+    for (int m = 0; m < mates; ++m) if (close(fds[m]) != 0) failed = true;
+    return failed ? SKM_ERR_IO : SKM_OK;
 }

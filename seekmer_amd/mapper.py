@@ -230,6 +230,10 @@ class MapResult:
         """Clear the counter (seekmer/mapper.py:143-145)."""
         _native.check(_native.hip().skm_mapper_clear(self._handle))
 
+    def sync(self):
+        """Wait for every batch handed over with map_batch_async; raises the first failure."""
+        _native.check(_native.hip().skm_mapper_sync(self._handle))
+
     def reset(self):
         """Fresh-MapResult state (counter, totals and histogram) on the same buffers."""
         _native.check(_native.hip().skm_mapper_reset(self._handle))
@@ -272,11 +276,23 @@ class ReadMapper:
         self.map_result = map_result
 
     def map_batch(self, batch):
-        """Map one batch; returns the per-unit results only when needed."""
+        """Map one batch and wait for it."""
         hip = _native.hip()
         _native.check(hip.skm_mapper_map_batch(
             self.map_result._handle, batch.bases.ctypes.data,
             _native.ptr(batch.offsets, _native.c_i64p), batch.count, int(batch.paired)))
+
+    def map_batch_async(self, batch):
+        """Hand one batch over (returns when its arrays are free again; the kernels run behind
+        the next batch's parsing and copy).  MapResult.sync() -- or any read of the result --
+        waits for what is queued.  A batch that knows its place in the sample
+        (``batch.first_unit``) keeps the -j1 class order whatever the submission order."""
+        hip = _native.hip()
+        first_unit = getattr(batch, 'first_unit', None)
+        _native.check(hip.skm_mapper_map_batch_async(
+            self.map_result._handle, batch.bases.ctypes.data,
+            _native.ptr(batch.offsets, _native.c_i64p), batch.count, int(batch.paired),
+            -1 if first_unit is None else int(first_unit)))
 
     def last_batch(self, n_units):
         """(begin, end, anchor_entry, anchor_offset, counts, signed entries); the spans need a
@@ -312,7 +328,7 @@ class ReadMapper:
                 read_count, read_names, reads = item
                 batch = ReadBatch.from_lists(read_count, read_names, reads)
             if self.map_result.readmap is None:
-                self.map_batch(batch)
+                self.map_batch_async(batch)
                 continue
             # -m/--save-readmap: the per-unit tuples of THIS batch are needed, so
             # keep other threads off the handle until they are fetched
@@ -323,6 +339,7 @@ class ReadMapper:
                 bounds = numpy.concatenate([[0], numpy.cumsum(counts)]).tolist()
                 tuples = [tuple(ids[bounds[i]:bounds[i + 1]]) for i in range(batch.count)]
                 self.map_result._write_readmap(batch.names, tuples)
+        self.map_result.sync()            # (raises here what a queued batch failed with)
 
 
 def _drain_worker(mapper, reads_queue, errors):

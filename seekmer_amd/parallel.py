@@ -93,3 +93,36 @@ def broadcast_comm_id(dist, rank, group=None):
         buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
     dist.broadcast(buf, 0, group=group)
     return bytes(buf.numpy().tobytes())
+
+
+def shared_index(build, rank, world, barrier=None, cache=None):
+    """One index for all ranks of a node: rank 0 builds it (or finds it in `cache`) and saves the
+    container, the others wait at `barrier` and map the same file (KMerIndex.load memory-maps
+    it, so the 2 GiB table exists once in the page cache instead of once per rank and is built
+    once instead of `world` times)."""
+    import os
+    import tempfile
+    from . import common
+    if world == 1 and not cache:
+        return build()
+    path = cache or os.path.join(tempfile.gettempdir(), 'skm_shared_index_%s.npz'
+                                 % os.environ.get('MASTER_PORT', str(os.getppid())))
+    index = None
+    if rank == 0:
+        if cache and os.path.exists(cache):
+            index = common.KMerIndex.load(cache)
+        else:
+            index = build()
+            index.save(path)
+    if barrier is not None:
+        barrier()
+    if index is None:
+        index = common.KMerIndex.load(path)
+    if barrier is not None:
+        barrier()
+    if rank == 0 and not cache and world > 1:
+        try:
+            os.unlink(path)          # (the other ranks hold their mappings)
+        except OSError:
+            pass
+    return index

@@ -44,6 +44,15 @@ def reads(seed, pool, offsets, first_unit, n_units, read_len, paired, n_threads=
     return bases, read_offsets
 
 
+def write_fastq(bases, n_units, read_len, paired, path1, path2=None, first_unit=0, n_threads=None):
+    """The batch of `reads()` as FASTQ text (one file per mate)."""
+    if n_threads is None:
+        n_threads = min(16, os.cpu_count() or 1)
+    _native.check_host(_native.host().skm_synth_fastq_write(
+        bases.ctypes.data, n_units, read_len, int(bool(paired)), first_unit, os.fsencode(str(path1)),
+        os.fsencode(str(path2)) if path2 is not None else None, n_threads), 'skm_synth_fastq_write')
+
+
 def sequences_of(pool, offsets):
     raw = pool.tobytes()
     return [raw[offsets[i]:offsets[i + 1]] for i in range(offsets.size - 1)]

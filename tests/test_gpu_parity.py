@@ -883,3 +883,73 @@ def test_module_surface(oracle, native_libs, chr21, chr21_oracle_index, pairs21,
     assert samples[0].counter == want
     single = oracle.map_batch(chr21_oracle_index, *oracle.pack_reads(pairs21[0::2]), 21, False)
     assert samples[1].counter == collections.Counter(single.tuples())
+
+
+def test_async_batches_from_host_and_from_fastq(oracle, native_libs, tmp_path):
+    """skm_mapper_map_batch_async: a sample handed over in pieces -- by one thread in order, by
+    three threads in any order, and as FASTQ text through the native reader's parallel engine
+    with page-locked slabs -- gives the table of the one-batch run bit for bit, class order
+    included (every piece carries its place in the sample, `first_unit`); the oracle pins that
+    table.  A piece with broken offsets fails the sync (not the process) and leaves the handle
+    usable after a reset."""
+    import threading
+    from seekmer_amd import synth, index_builder, mapper, common
+    ids, pool, tx_offsets = synth.transcriptome(6, 60)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    oindex = oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                                lengths=np.diff(tx_offsets))
+    n_units, read_len = 60000, 75
+    bases, offsets = synth.reads(6, pool, tx_offsets, 0, n_units, read_len, True)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(oindex, bases, offsets, n_units, True, fld)
+    whole = mapper.MapResult(index)
+    mapper.ReadMapper(index, whole).map_batch(common.ReadBatch(n_units, bases, offsets, True))
+    _compare_tables(oracle, expected, fld, whole)
+    reference = whole.export()
+
+    cut = [0, 7000, 7001, 25000, 41000, n_units]
+    pieces = [common.ReadBatch(cut[k + 1] - cut[k], bases, offsets[2 * cut[k]:2 * cut[k + 1] + 1], True,
+                               first_unit=cut[k]) for k in range(len(cut) - 1)]
+
+    def same(result):
+        for got, want in zip(result.export(), reference):
+            np.testing.assert_array_equal(got, want)
+        assert result.sizes() == whole.sizes()
+
+    one = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, one)
+    for piece in pieces:
+        rm.map_batch_async(piece)
+    one.sync()
+    same(one)
+
+    many = mapper.MapResult(index)
+    order = [3, 0, 4, 2, 1]
+    threads = [threading.Thread(target=lambda ks=ks: [mapper.ReadMapper(index, many).map_batch_async(pieces[k])
+                                                      for k in ks])
+               for ks in (order[:2], order[2:4], order[4:])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    same(many)                                           # (export waits for the queue)
+
+    p1, p2 = tmp_path / 'r_1.fastq', tmp_path / 'r_2.fastq'
+    synth.write_fastq(bases, n_units, read_len, True, p1, p2)
+    for threads_, pinned in ((0, False), (3, True)):
+        feeder = common.NativeReadFeeder([p1, p2], True, batch_units=9000, threads=threads_, pinned=pinned)
+        text = mapper.map_reads(index, feeder, job_count=1 if threads_ == 0 else 3)
+        assert feeder.parallel is (threads_ > 0)
+        same(text)
+
+    broken = offsets[:2 * 500 + 1].copy()
+    broken[100] = broken[101] + 5
+    one.reset()
+    rm.map_batch_async(pieces[0])
+    rm.map_batch_async(common.ReadBatch(500, bases, broken, True))
+    with pytest.raises(ValueError):
+        one.sync()
+    one.reset()
+    for piece in pieces:
+        rm.map_batch_async(piece)
+    same(one)

@@ -367,6 +367,9 @@ class _StubResult:
         self.index = index
         self.batches = 0
 
+    def sync(self):
+        pass
+
 
 @pytest.mark.timeout(60)
 @pytest.mark.parametrize('job_count', [1, 3])
@@ -381,15 +384,70 @@ def test_map_reads_reraises_a_worker_failure(native_libs, monkeypatch, job_count
             if self.map_result.batches == 2:
                 raise _native.NativeError(2, 'skm_mapper_map_batch: GPU out of memory (stub)')
     monkeypatch.setattr(mapper, 'MapResult', _StubResult)
-    monkeypatch.setattr(mapper.ReadMapper, 'map_batch', map_batch)
+    monkeypatch.setattr(mapper.ReadMapper, 'map_batch_async', map_batch)
     batches = [common.ReadBatch.from_lists(1, [b'r'], [b'ACGT' * 10]) for _ in range(40)]
     with pytest.raises(_native.NativeError):
         mapper.map_reads(object(), iter(batches), job_count=job_count)
     # and without a failure every batch is consumed
-    monkeypatch.setattr(mapper.ReadMapper, 'map_batch',
+    monkeypatch.setattr(mapper.ReadMapper, 'map_batch_async',
                         lambda self, batch: setattr(self.map_result, 'batches', self.map_result.batches + 1))
     done = mapper.map_reads(object(), iter(batches), job_count=1)
     assert done.batches == 40
     with pytest.raises(_native.NativeError):
-        monkeypatch.setattr(mapper.ReadMapper, 'map_batch', map_batch)
+        monkeypatch.setattr(mapper.ReadMapper, 'map_batch_async', map_batch)
         mapper.map_multiple_samples(object(), [iter(batches[:3]), iter(batches[:1])], job_count=2)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('paired', [True, False])
+def test_parallel_fastq_engine_equals_sequential(native_libs, tmp_path, paired):
+    """The parallel engine of the native reader (memory-mapped files, newline index, whole
+    batches parsed side by side) hands out exactly the batches of the sequential engine --
+    ragged read lengths, CRLF, padding blanks, a quality line that starts with '@', several
+    files with a batch carried across the file boundary, a last line without newline -- and
+    files it cannot split exactly (line count not a multiple of four) fall back silently."""
+    from seekmer_amd import common
+    rng = np.random.default_rng(12)
+
+    def write(path, n, mate, last_newline=True):
+        lines = []
+        for i in range(n):
+            m = int(rng.integers(25, 160))
+            seq = bytes(rng.choice(list(b'ACGTNacgt'), m).astype(np.uint8))
+            eol = b'\r\n' if i % 11 == 0 else b'\n'
+            qual = (b'@' if i % 5 == 0 else b'I') + b'I' * (m - 1)
+            lines += [b'@r%d/%d some text' % (i, mate) + eol, (b' ' if i % 7 == 0 else b'') + seq + eol,
+                      b'+' + eol, qual + eol]
+        text = b''.join(lines)
+        path.write_bytes(text if last_newline else text.rstrip(b'\r\n'))
+
+    counts = (3001, 1777)
+    paths = []
+    for f, n in enumerate(counts):
+        for mate in ((1, 2) if paired else (1,)):
+            path = tmp_path / ('s%d_%d.fastq' % (f, mate))
+            write(path, n, mate, last_newline=not (f == 1 and mate == 1))
+            paths.append(path)
+    sequential = [(b.count, b.names, b.reads, b.first_unit) for b in
+                  common.NativeReadFeeder(paths, paired=paired, batch_units=700)]
+    feeder = common.NativeReadFeeder(paths, paired=paired, batch_units=700, threads=3)
+    parallel = [(b.count, b.names, b.reads, b.first_unit) for b in feeder]
+    assert feeder.parallel is True
+    assert parallel == sequential
+    assert [p[0] for p in parallel] == [700] * 6 + [sum(counts) - 4200]
+    assert [p[3] for p in parallel] == [700 * k for k in range(7)]
+    # leaving the loop early with workers in flight must not hang or leak
+    it = iter(common.NativeReadFeeder(paths, paired=paired, batch_units=100, threads=4))
+    assert next(it).count == 100
+    it.close()
+    # a file with a dangling name line: not splittable exactly -> sequential engine, same result
+    width = 2 if paired else 1                      # (zip() stops at the shorter file: both mates dangle)
+    others = list(paths)
+    for mate in range(width):
+        ragged = tmp_path / ('ragged_%d.fastq' % (mate + 1))
+        ragged.write_bytes(paths[mate].read_bytes() + b'@dangling\n')
+        others[mate] = ragged
+    feeder = common.NativeReadFeeder(others, paired=paired, batch_units=700, threads=3)
+    got = [(b.count, b.reads) for b in feeder]
+    assert feeder.parallel is False
+    assert got == [(b.count, b.reads) for b in common.NativeReadFeeder(others, paired=paired, batch_units=700)]
