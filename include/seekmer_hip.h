@@ -261,6 +261,12 @@ int skm_fastq_open(const char *const *paths, int n_paths, int paired,
  * line counts are multiples of four; *enabled = 0 (and the sequential engine stays) otherwise. */
 int skm_fastq_set_allocator(skm_fastq *reader, void *(*alloc)(size_t), void (*release)(void *));
 int skm_fastq_set_parallel(skm_fastq *reader, int n_threads, int *enabled);
+/* Several readers, one sample (one rank per GPU): reader `rank` of `world` hands out the
+ * batches k with k % world == rank (the parallel engine parses only those; the sequential
+ * engine has to read past the others).  skm_fastq_batch_index: k of the batch handed out last
+ * -- its first unit is k * batch_units of the whole sample. */
+int skm_fastq_set_shard(skm_fastq *reader, int rank, int world);
+int skm_fastq_batch_index(const skm_fastq *reader, int64_t *index);
 /* next batch: *n_units = 0 at end.  Buffers are owned by the reader and stay
  * valid until the next call.  names: '\n'-separated. */
 int skm_fastq_next(skm_fastq *reader, int64_t *n_units, const char **bases,

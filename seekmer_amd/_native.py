@@ -100,6 +100,8 @@ HOST_SYMBOLS = {
                                       c_i64, c_void_pp]),
     'skm_fastq_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_set_parallel': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'skm_fastq_set_shard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'skm_fastq_batch_index': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_fastq_next': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_void_pp, c_void_pp, c_void_pp,
                                       c_void_pp]),
     'skm_fastq_detach': (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),

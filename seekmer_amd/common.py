@@ -296,7 +296,7 @@ class _FastqReader:
     """Owns one skm_fastq handle; closed when the feeder loop and every batch
     that borrowed a slab from it are gone."""
 
-    def __init__(self, names, paired, batch_units, threads=0, pinned=False):
+    def __init__(self, names, paired, batch_units, threads=0, pinned=False, shard=None):
         array = (ctypes.c_char_p * len(names))(*names)
         self.handle = ctypes.c_void_p()
         self.lock = threading.Lock()
@@ -310,6 +310,9 @@ class _FastqReader:
             _native.check_host(host.skm_fastq_set_allocator(
                 self.handle, ctypes.cast(hip.skm_pinned_alloc, ctypes.c_void_p),
                 ctypes.cast(hip.skm_pinned_free, ctypes.c_void_p)), 'skm_fastq_set_allocator')
+        if shard is not None and shard[1] > 1:
+            _native.check_host(host.skm_fastq_set_shard(self.handle, int(shard[0]), int(shard[1])),
+                               'skm_fastq_set_shard')
         if threads > 0:
             enabled = ctypes.c_int(0)
             _native.check_host(host.skm_fastq_set_parallel(self.handle, int(threads), ctypes.byref(enabled)),
@@ -360,9 +363,10 @@ class NativeReadFeeder:
     are multiples of four: whole batches parsed side by side, handed out in file order; any
     other input silently takes the sequential engine).  ``pinned`` puts the slabs in
     page-locked memory (needs the GPU library).  Every batch carries ``first_unit``, its place
-    in the sample."""
+    in the sample.  ``shard=(rank, world)``: this feeder hands out every world-th batch of the
+    sample starting with batch `rank` (one feeder per GPU, no coordination needed)."""
 
-    def __init__(self, paths, paired, batch_units=BUFFER_SIZE, threads=0, pinned=False):
+    def __init__(self, paths, paired, batch_units=BUFFER_SIZE, threads=0, pinned=False, shard=None):
         paths = [pathlib.Path(p) for p in paths]
         if paired and len(paths) % 2 != 0:
             raise ValueError('cannot process odd numbers of pair-ended files')
@@ -371,6 +375,7 @@ class NativeReadFeeder:
         self.batch_units = int(batch_units)
         self.threads = int(threads)
         self.pinned = bool(pinned)
+        self.shard = shard                   # (rank, world): this feeder's share of the sample's batches
         self.parallel = None                 # set when iteration starts
 
     def __iter__(self):
@@ -388,10 +393,10 @@ class NativeReadFeeder:
                 else:
                     names.append(str(path).encode())
             threads = 0 if processes else self.threads          # (pipes are read sequentially)
-            reader = _FastqReader(names, self.paired, self.batch_units, threads, self.pinned)
+            reader = _FastqReader(names, self.paired, self.batch_units, threads, self.pinned, self.shard)
             self.parallel = reader.parallel
-            first_unit = 0
             n = ctypes.c_int64()
+            k = ctypes.c_int64()
             p_bases, p_off = ctypes.c_void_p(), ctypes.c_void_p()
             p_names, p_noff = ctypes.c_void_p(), ctypes.c_void_p()
             while True:
@@ -415,9 +420,10 @@ class NativeReadFeeder:
                 bases = view(p_bases, int(offsets[-1]) + 1, ctypes.c_uint8, numpy.uint8)
                 name_offsets = view(p_noff, n.value + 1, ctypes.c_int64, numpy.int64)
                 name_bytes = view(p_names, max(int(name_offsets[-1]), 1), ctypes.c_uint8, numpy.uint8)
+                _native.check_host(host.skm_fastq_batch_index(reader.handle, ctypes.byref(k)),
+                                   'skm_fastq_batch_index')
                 batch = ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets,
-                                  first_unit=first_unit)
-                first_unit += n.value
+                                  first_unit=k.value * self.batch_units)
                 yield batch
                 del batch, owner, bases, offsets, name_bytes, name_offsets, view
         finally:

@@ -238,6 +238,9 @@ struct skm_fastq {
     int64_t batch_units = 65536;
     alloc_fn al = malloc;
     free_fn fr = free;
+    int shard_rank = 0, shard_world = 1;      // this reader hands out batches k with k % world == rank
+    int64_t seq_batch = 0;                    // sequential engine: index of the next batch it parses
+    int64_t last_index = -1;                  // index (in the whole sample) of the batch handed out last
     // ---- sequential engine
     size_t next_path = 0;
     LineReader r1, r2;
@@ -363,6 +366,11 @@ struct skm_fastq {
         out->units += u1 - u0;
     }
 
+    int64_t own_batches() const
+    {
+        return n_batches > shard_rank ? (n_batches - shard_rank + shard_world - 1) / shard_world : 0;
+    }
+
     void build_batch(int64_t k, skm_fastq_slab *out)
     {
         const int64_t g0 = k * batch_units, g1 = std::min(total_units, g0 + batch_units);
@@ -382,10 +390,12 @@ struct skm_fastq {
             int64_t k;
             {
                 std::unique_lock<std::mutex> hold(pm);
+                // (next_claim / next_deliver count THIS reader's batches: number j is batch
+                // shard_rank + j * shard_world of the sample)
                 pcv.wait(hold, [&] {
-                    return stop || (next_claim < n_batches && next_claim < next_deliver + n_threads + 1);
+                    return stop || next_claim >= own_batches() || next_claim < next_deliver + n_threads + 1;
                 });
-                if (stop || next_claim >= n_batches) return;
+                if (stop || next_claim >= own_batches()) return;
                 k = next_claim++;
             }
             const bool trace = getenv("SKM_FASTQ_TRACE") != nullptr;
@@ -393,7 +403,7 @@ struct skm_fastq {
             skm_fastq_slab *slab = take_slab();
             const size_t cap_before = slab->bases.cap;
             const auto t1 = std::chrono::steady_clock::now();
-            build_batch(k, slab);
+            build_batch(shard_rank + k * shard_world, slab);
             if (trace)
                 fprintf(stderr, "[skm_fastq] batch %lld: slab %.1f ms (capacity %zu -> %zu), parse %.1f ms, %lld units\n", (long long)k,
                         std::chrono::duration<double, std::milli>(t1 - t0).count(), cap_before, slab->bases.cap,
@@ -501,11 +511,11 @@ extern "C" int skm_fastq_recycle(skm_fastq *q, skm_fastq_slab *slab);
 
 static int next_parallel(skm_fastq *q, int64_t *n_units)
 {
-    if (q->workers.empty() && q->next_deliver < q->n_batches)
+    if (q->workers.empty() && q->next_deliver < q->own_batches())
         for (int t = 0; t < q->n_threads; ++t) q->workers.emplace_back([q]() { q->worker_main(); });
     if (q->cur) skm_fastq_recycle(q, q->cur);   // (a batch that was not detached)
     q->cur = nullptr;
-    if (q->next_deliver >= q->n_batches) {
+    if (q->next_deliver >= q->own_batches()) {
         q->cur = new skm_fastq_slab();          // (an empty batch of its own: the pooled slabs stay pooled)
         q->cur->start();
         q->cur->bases.push(0);
@@ -522,6 +532,7 @@ static int next_parallel(skm_fastq *q, int64_t *n_units)
                 (long long)q->next_deliver);
     q->cur = q->ready[q->next_deliver];
     q->ready.erase(q->next_deliver);
+    q->last_index = q->shard_rank + q->next_deliver * q->shard_world;
     q->next_deliver++;
     const bool failed = q->failed;
     hold.unlock();
@@ -546,6 +557,7 @@ extern "C" int skm_fastq_next(skm_fastq *q, int64_t *n_units, const char **bases
         if (name_offsets) *name_offsets = b->name_offsets.p;
         return SKM_OK;
     }
+    for (;;) {
     q->reset_batch();
     skm_fastq_slab *const b = q->cur;
     bool full = false;
@@ -595,10 +607,31 @@ extern "C" int skm_fastq_next(skm_fastq *q, int64_t *n_units, const char **bases
     b->bases.push(0);
     if (b->names.n == 0) b->names.reserve(1);
     if (b->failed()) return SKM_ERR_IO;
+    // a sharded reader parses everything (a pipe cannot be skipped through) and hands out its own
+    const int64_t index = q->seq_batch++;
+    if (*n_units != 0 && index % q->shard_world != q->shard_rank) continue;
+    q->last_index = index;
     if (bases) *bases = b->bases.p;
     if (offsets) *offsets = b->offsets.p;
     if (names) *names = b->names.p;
     if (name_offsets) *name_offsets = b->name_offsets.p;
+    return SKM_OK;
+    }
+}
+
+extern "C" int skm_fastq_set_shard(skm_fastq *q, int rank, int world)
+{
+    if (!q || world < 1 || rank < 0 || rank >= world) return SKM_ERR_ARG;
+    if (q->open || q->finished || q->next_path || !q->workers.empty() || q->next_deliver) return SKM_ERR_STATE;
+    q->shard_rank = rank;
+    q->shard_world = world;
+    return SKM_OK;
+}
+
+extern "C" int skm_fastq_batch_index(const skm_fastq *q, int64_t *index)
+{
+    if (!q || !index) return SKM_ERR_ARG;
+    *index = q->last_index;
     return SKM_OK;
 }
 

@@ -26,33 +26,73 @@ X_FLOOR = 1e-8          # seekmer/infer.py:160
 
 
 def run(index_path, output_path, fastq_paths, job_count, save_readmap,
-        single_ended, bootstrap, debug, device=0, seed=None, **__):
-    """The entrypoint of the inference module (seekmer/infer.py:27-85)."""
+        single_ended, bootstrap, debug, device=0, seed=None, parse_threads=0, **__):
+    """The entrypoint of the inference module (seekmer/infer.py:27-85).
+
+    Started as one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m
+    seekmer_amd infer ...`) the sample is shared out batch by batch: every rank maps its
+    batches on its own GPU against its own replica of the index, the EM runs over the rank-local
+    class tables with one RCCL all-reduce per step, and rank 0 -- after merging the ranks' tables
+    on its GPU -- writes the outputs of the whole sample."""
+    from . import parallel
     start_time = datetime.datetime.utcnow()
-    try:
-        output_path.mkdir(parents=True)
-    except FileExistsError:
-        _LOG.warning('The output folder exists. Overriding...')
+    ranks = parallel.Ranks.from_env()
+    if ranks.world > 1:
+        device = ranks.local_rank
+        if save_readmap:
+            raise ValueError('-m/--save-readmap needs the reads of the whole sample in one process: run it on one GPU')
+    if ranks.rank == 0:
+        try:
+            output_path.mkdir(parents=True)
+        except FileExistsError:
+            _LOG.warning('The output folder exists. Overriding...')
+    ranks.barrier()
     readmap = (output_path / 'readmap.txt').open('wt') if save_readmap else None
     _LOG.info('Inferring transcript abundance')
     index = common.KMerIndex.load(index_path)
     _LOG.info('Mapping all reads')
-    read_feeder = common.NativeReadFeeder(fastq_paths, paired=not single_ended)
+    read_feeder = common.NativeReadFeeder(fastq_paths, paired=not single_ended, threads=parse_threads,
+                                          pinned=parse_threads > 0, shard=ranks.shard)
     map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
                                   readmap=readmap, debug=debug, device=device)
     _LOG.info('Mapped all reads')
-    _LOG.info('Estimated fragment length: %.2f', map_result.harmonic_mean_fragment_length)
-    summarized_results = map_result.summarize()
+    comm = parallel.make_comm(ranks, device)
+    try:
+        summarized_results, main_result = finish(map_result, ranks,
+                                                 lambda result: quantify_resident(result, comm=comm))
+    finally:
+        parallel.destroy_comm(comm)
+    if ranks.rank == 0:
+        _LOG.info('Estimated fragment length: %.2f', map_result.harmonic_mean_fragment_length)
+        _LOG.info('Aligned %d reads (%.2f%%)', summarized_results.aligned,
+                  100.0 * summarized_results.aligned / summarized_results.total)
+        _LOG.info('Quantified transcripts')
+        bootstrapped_results = bootstrap_quantify(summarized_results, main_result, bootstrap,
+                                                  seed=seed)
+        output_results(output_path, index, start_time, summarized_results,
+                       main_result, bootstrapped_results)
+        _LOG.info('Wrote results to %s', output_path)
+    ranks.close()
+
+
+def finish(map_result, ranks, quantify_ranks):
+    """From the ranks' tables to the sample's results.  One rank: summarize + quantify as the
+    reference does (seekmer/infer.py:66-78).  Several: `quantify_ranks(map_result)` runs the EM
+    over the rank-local tables (collectives inside; every rank gets the TPM of the whole sample),
+    THEN the other ranks' tables go to rank 0 and are merged into its own, whose summary is the
+    whole sample's: (SummarizedResult, TPM) on rank 0, (None, TPM) elsewhere."""
+    from . import parallel
+    if ranks.world == 1:
+        summarized = map_result.summarize()
+        _LOG.info('Quantifying transcripts')
+        return summarized, quantify(summarized)
     _LOG.info('Quantifying transcripts')
-    _LOG.info('Aligned %d reads (%.2f%%)', summarized_results.aligned,
-              100.0 * summarized_results.aligned / summarized_results.total)
-    main_result = quantify(summarized_results)
-    _LOG.info('Quantified transcripts')
-    bootstrapped_results = bootstrap_quantify(summarized_results, main_result, bootstrap,
-                                              seed=seed)
-    output_results(output_path, index, start_time, summarized_results,
-                   main_result, bootstrapped_results)
-    _LOG.info('Wrote results to %s', output_path)
+    tpm = quantify_ranks(map_result)
+    tables = ranks.gather_to_root(parallel.rank_table(map_result) if ranks.rank else None)
+    if ranks.rank != 0:
+        return None, tpm
+    parallel.merge_into(map_result, tables[1:])
+    return map_result.summarize(), tpm
 
 
 # ------------------------------------------------------------- device tables
@@ -340,3 +380,5 @@ def add_subcommand_parser(subparsers):
     parser.add_argument('--device', type=int, default=0, help='GPU ordinal (default 0)')
     parser.add_argument('--seed', type=int, default=None,
                         help='seed of the bootstrap resampling (default: random)')
+    parser.add_argument('--parse-threads', type=int, dest='parse_threads', default=0, metavar='N',
+                        help='parse plain FASTQ files with N threads into page-locked memory (default: 1 thread)')

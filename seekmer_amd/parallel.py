@@ -95,6 +95,93 @@ def broadcast_comm_id(dist, rank, group=None):
     return bytes(buf.numpy().tobytes())
 
 
+class Ranks:
+    """This process's place in a one-process-per-GPU job, as `python -m torch.distributed.run
+    --nproc-per-node N` describes it in the environment (RANK, WORLD_SIZE, LOCAL_RANK,
+    MASTER_ADDR/PORT).  With WORLD_SIZE > 1 a gloo process group is opened for the host-side
+    exchanges (rendezvous, the RCCL id, class tables to rank 0); nothing here touches the GPU,
+    so a launcher may still start the ranks after this has been read."""
+
+    def __init__(self, rank=0, world=1, local_rank=0, dist=None, owns_group=False):
+        self.rank, self.world, self.local_rank = int(rank), int(world), int(local_rank)
+        self.dist = dist
+        self._owns_group = owns_group
+
+    @classmethod
+    def from_env(cls, backend='gloo'):
+        import os
+        rank = int(os.environ.get('RANK', '0'))
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+        if world <= 1:
+            return cls()
+        import torch.distributed as dist
+        owns = False
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            owns = True
+        return cls(rank, world, local_rank, dist, owns)
+
+    @property
+    def shard(self):
+        return (self.rank, self.world) if self.world > 1 else None
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gather_to_root(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on rank 0, None elsewhere."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, out, dst=0)
+        return out
+
+    def close(self):
+        if self.dist is not None and self._owns_group:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        self.dist = None
+
+
+def make_comm(ranks, device):
+    """One RCCL communicator per process (skm_comm*), or None for a single rank."""
+    import ctypes
+    from . import _native
+    if ranks.world <= 1:
+        return None
+    comm_id = broadcast_comm_id(ranks.dist, ranks.rank)
+    comm = ctypes.c_void_p()
+    _native.check(_native.hip().skm_comm_create(device, comm_id, ranks.rank, ranks.world, ctypes.byref(comm)))
+    return comm
+
+
+def destroy_comm(comm):
+    from . import _native
+    if comm:
+        _native.check(_native.hip().skm_comm_destroy(comm))
+
+
+def rank_table(map_result):
+    """What rank 0 needs from a rank after mapping: its class table (first-seen values are global
+    unit indices already: every batch was mapped with its `first_unit`), the unaligned count and
+    the rank's fragment-length histogram."""
+    offsets, targets, counts, first_seen, fld = map_result.export()
+    return {'offsets': offsets, 'targets': targets, 'counts': counts, 'first_seen': first_seen,
+            'unaligned': map_result.sizes()[2], 'fld': fld}
+
+
+def merge_into(map_result, tables):
+    """Counter.update + merge_fragment_lengths with the other ranks' tables, on the GPU
+    (skm_mapper_merge): rank 0's table becomes the table of the whole sample, classes in the
+    order a single -j1 run would have met them."""
+    for table in tables:
+        map_result.merge_table(table['offsets'], table['targets'], table['counts'], table['first_seen'],
+                               table['unaligned'], table['fld'])
+
+
 def shared_index(build, rank, world, barrier=None, cache=None):
     """One index for all ranks of a node: rank 0 builds it (or finds it in `cache`) and saves the
     container, the others wait at `barrier` and map the same file (KMerIndex.load memory-maps

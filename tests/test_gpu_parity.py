@@ -600,6 +600,11 @@ def test_cli_end_to_end(oracle, native_libs, chr21, chr21_oracle_index, pairs21,
     arrays = np.load(out / 'abundance.npz')
     assert arrays['bootstrap/bs2'].shape == (len(chr21[0]),)
     np.testing.assert_array_equal(arrays['aux/fld'], fld.astype('i4'))
+    # the same sample through the parallel FASTQ engine, page-locked slabs and three mapping threads
+    out2 = tmp_path / 'out2'
+    assert cli.main(['infer', str(index_path), str(out2), os.path.join(GOLDEN, '20_1.fastq'),
+                     os.path.join(GOLDEN, '20_2.fastq'), '-j', '3', '--parse-threads', '2']) == 0
+    assert (out2 / 'abundance.tsv').read_text() == (out / 'abundance.tsv').read_text()
 
 
 def test_full_size_properties(oracle, native_libs):

@@ -451,3 +451,27 @@ def test_parallel_fastq_engine_equals_sequential(native_libs, tmp_path, paired):
     got = [(b.count, b.reads) for b in feeder]
     assert feeder.parallel is False
     assert got == [(b.count, b.reads) for b in common.NativeReadFeeder(others, paired=paired, batch_units=700)]
+
+
+@pytest.mark.parametrize('threads', [0, 3])
+def test_sharded_feeders_partition_the_sample(native_libs, tmp_path, threads):
+    """shard=(rank, world): the feeders of the ranks hand out disjoint batches whose union, put
+    back in first_unit order, is the unsharded sequence of batches (both engines)."""
+    from seekmer_amd import common
+    lines = []
+    for i in range(2300):
+        lines += [b'@r%d\n' % i, b'ACGT' * 8 + b'%04d' % i + b'\n', b'+\n', b'I' * 36 + b'\n']
+    path = tmp_path / 'r.fastq'
+    path.write_bytes(b''.join(lines))
+    whole = [(b.first_unit, b.count, b.reads) for b in
+             common.NativeReadFeeder([path], paired=False, batch_units=300, threads=threads)]
+    assert [w[0] for w in whole] == [300 * k for k in range(8)]
+    for world in (2, 3, 9):
+        parts = []
+        for rank in range(world):
+            mine = [(b.first_unit, b.count, b.reads) for b in
+                    common.NativeReadFeeder([path], paired=False, batch_units=300, threads=threads,
+                                            shard=(rank, world))]
+            assert [m[0] // 300 % world for m in mine] == [rank] * len(mine)
+            parts += mine
+        assert sorted(parts) == whole

@@ -1,8 +1,12 @@
-"""The N > 1 path on CPU: world_size 2, gloo.  Each rank maps its shard (with
-the oracle as the compute stand-in -- no GPU here), then the PRODUCT's host
-logic (seekmer_amd.parallel) all-reduces the histogram, gathers and merges the
-class tables; the result must equal one process mapping everything, and one
-sharded EM step (local numerators + all-reduce) must equal the global step."""
+"""The N > 1 path on CPU: world_size 2, gloo, driving the PRODUCT's host-side rank logic --
+`parallel.Ranks.from_env`, the sharded `NativeReadFeeder`, `infer.finish` (quantify over the
+rank-local tables first, then tables to rank 0, merge, summarize), `parallel.rank_table /
+merge_into`.  There is no GPU here, so the two device-backed pieces are stood in for by the
+oracle: a MapResult whose table is filled by the oracle's mapper, and a `quantify_ranks` that
+runs the reference's EM with one all-reduce of the per-transcript numerators per step -- the
+collective pattern of skm_quant_infer(comm).  Rank 0's results must equal one process mapping the
+whole sample: class table bit for bit (order included), histogram, counts, and the TPM of the
+sharded EM against the oracle's EM on the merged table (same iteration count, 1e-9)."""
 import os
 import socket
 import sys
@@ -19,69 +23,157 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, queue):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import torch.distributed as dist
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        from oracle import oracle as O
-        from seekmer_amd import parallel, synth
-        ids, pool, tx_offsets = synth.transcriptome(4, 30)
-        index = O.build_index(synth.sequences_of(pool, tx_offsets))
-        n_units = 6001
-        first, count = parallel.shard_range(n_units, rank, world)
-        bases, offsets = synth.reads(4, pool, tx_offsets, first, count, 75, True, n_threads=1)
-        fld = np.zeros(2000, dtype=np.int64)
-        result = O.map_batch(index, bases, offsets, count, True, fld)
-        classes = O.Classes()
-        classes.update(result)
-        offs, targets, counts = classes.export()
-        # first-seen unit of each class within this shard, made global
-        tuples = result.tuples()
-        seen = {}
-        for u, t in enumerate(tuples):
-            if t and t not in seen:
-                seen[t] = u
-        tl = targets.tolist()
-        first_seen = np.asarray([seen[tuple(tl[offs[k]:offs[k + 1]])] + first
-                                 for k in range(counts.size)], dtype=np.int64)
-        table = {'offsets': offs, 'targets': targets, 'counts': counts, 'first_seen': first_seen,
-                 'unaligned': classes.unaligned}
-        global_fld = parallel.allreduce_fld(fld, dist)
-        merged = parallel.merge_class_tables(parallel.gather_tables(table, dist))
+N_UNITS, READ_LEN, BATCH = 6001, 75, 700
 
-        # one sharded EM step: local numerators, all-reduce, finalise
-        import torch
-        eff = O.effective_lengths(global_fld, index.lengths)
+
+def _sample(tmp):
+    """(oracle index, transcript pool, FASTQ paths) of the test sample, written once."""
+    from oracle import oracle as O
+    from seekmer_amd import synth
+    ids, pool, tx_offsets = synth.transcriptome(4, 30)
+    index = O.build_index(synth.sequences_of(pool, tx_offsets))
+    p1, p2 = os.path.join(tmp, 'r_1.fastq'), os.path.join(tmp, 'r_2.fastq')
+    if not os.path.exists(p2):
+        bases, _ = synth.reads(4, pool, tx_offsets, 0, N_UNITS, READ_LEN, True, n_threads=1)
+        synth.write_fastq(bases, N_UNITS, READ_LEN, True, p1, p2, n_threads=1)
+    return index, (p1, p2)
+
+
+class OracleMapResult:
+    """The MapResult surface infer.finish / parallel use, with the oracle doing the mapping."""
+
+    def __init__(self, O, index):
+        self.O, self.index = O, index
+        self.table = {}                       # tuple -> [count, first_seen]
+        self.unaligned = 0
+        self.fld = np.zeros(2000, dtype=np.int64)
+
+    def map_batch(self, batch):
+        fld = np.zeros(2000, dtype=np.int64)
+        result = self.O.map_batch(self.index, batch.bases, batch.offsets, batch.count, batch.paired, fld)
+        self.fld += fld
+        for u, t in enumerate(result.tuples()):
+            if not t:
+                self.unaligned += 1
+                continue
+            entry = self.table.setdefault(t, [0, batch.first_unit + u])
+            entry[0] += 1
+            entry[1] = min(entry[1], batch.first_unit + u)
+
+    def _ordered(self):
+        return sorted(self.table.items(), key=lambda kv: kv[1][1])
+
+    def export(self):
+        rows = self._ordered()
+        offsets = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum([len(k) for k, _ in rows], out=offsets[1:])
+        targets = np.asarray([t for k, _ in rows for t in k], dtype=np.int32)
+        return (offsets, targets, np.asarray([v[0] for _, v in rows], dtype=np.int64),
+                np.asarray([v[1] for _, v in rows], dtype=np.int64), self.fld.copy())
+
+    def sizes(self):
+        return (len(self.table), sum(len(k) for k in self.table), self.unaligned,
+                self.unaligned + sum(v[0] for v in self.table.values()))
+
+    def merge_table(self, offsets, targets, counts, first_seen, unaligned, fld):
+        ids = np.asarray(targets).tolist()
+        for k in range(len(counts)):
+            key = tuple(ids[offsets[k]:offsets[k + 1]])
+            entry = self.table.setdefault(key, [0, int(first_seen[k])])
+            entry[0] += int(counts[k])
+            entry[1] = min(entry[1], int(first_seen[k]))
+        self.unaligned += int(unaligned)
+        self.fld += np.asarray(fld, dtype=np.int64)
+
+    def summarize(self):
+        from seekmer_amd import mapper
+        offsets, targets, counts, _, fld = self.export()
+        class_ids = np.repeat(np.arange(counts.size, dtype=np.int64), np.diff(offsets))
+        aligned = int(counts.sum())
+        return mapper.SummarizedResult(
+            aligned=aligned, unaligned=self.unaligned, total=aligned + self.unaligned,
+            class_map=np.vstack([class_ids, targets.astype(np.int64)]), class_count=counts.astype('f8'),
+            fragment_length_frequencies=fld, effective_lengths=self.O.effective_lengths(fld, self.index.lengths),
+            class_offsets=offsets, class_targets=targets)
+
+
+def _quantify_ranks(O, index, ranks):
+    """quantify() over rank-local tables: the histogram and n all-reduced once, the numerators
+    all-reduced every step, the stopping rule judged redundantly (seekmer/infer.py:88-168)."""
+    import torch
+
+    def allreduce(a):
+        t = torch.from_numpy(np.ascontiguousarray(a).copy())
+        ranks.dist.all_reduce(t)
+        return t.numpy()
+
+    def run(result):
+        offsets, targets, counts, _, fld = result.export()
+        eff = O.effective_lengths(allreduce(fld), index.lengths)
+        n = float(allreduce(np.asarray([counts.sum()], dtype='f8'))[0])
+        cls = np.repeat(np.arange(counts.size), np.diff(offsets))
         x = 1.0 / eff
         x /= x.sum()
-        cls = np.repeat(np.arange(counts.size), np.diff(offs))
-        w = x[targets]
-        inner = np.bincount(cls, weights=w, minlength=counts.size) / counts
-        local = np.bincount(targets, weights=w / inner[cls], minlength=eff.size)
-        n_local = torch.tensor([float(counts.sum())], dtype=torch.float64)
-        t = torch.from_numpy(local)
-        dist.all_reduce(t)
-        dist.all_reduce(n_local)
-        x_new = t.numpy() / eff / float(n_local[0])
-        x_new[x_new != x_new] = 0
+        steps = 0
+        while True:
+            w = x[targets]
+            inner = np.bincount(cls, weights=w, minlength=counts.size) / counts
+            local = np.bincount(targets, weights=w / inner[cls], minlength=eff.size)
+            new = allreduce(local) / eff / n
+            new[new != new] = 0
+            steps += 1
+            change = (np.absolute(new - x) / new)[new > 1e-8].max()
+            x = new
+            if not change > 0.01:
+                break
+        x /= x.sum() / 1000000
+        x[x < 0.001] = 0
+        x /= x.sum() / 1000000
+        run.steps = steps
+        return x
+    return run
+
+
+def _worker(rank, world, port, tmp, queue):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update({'RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    from oracle import oracle as O
+    from seekmer_amd import common, infer, parallel
+    ranks = parallel.Ranks.from_env()
+    try:
+        assert (ranks.rank, ranks.world, ranks.local_rank) == (rank, world, rank) and ranks.shard == (rank, world)
+        index, paths = _sample(tmp)
+        result = OracleMapResult(O, index)
+        mine = []
+        for batch in common.NativeReadFeeder(paths, paired=True, batch_units=BATCH, threads=2 * rank,
+                                             shard=ranks.shard):
+            mine.append(batch.first_unit)
+            result.map_batch(batch)
+        assert mine == [BATCH * k for k in range(rank, (N_UNITS + BATCH - 1) // BATCH, world)]
+        quantify = _quantify_ranks(O, index, ranks)
+        summarized, tpm = infer.finish(result, ranks, quantify)
+        everyone = ranks.gather_to_root(tpm)
         if rank == 0:
-            queue.put({'fld': global_fld, 'merged': merged, 'x_new': x_new})
+            assert all(np.array_equal(t, tpm) for t in everyone)          # every rank holds the same TPM
+            queue.put({'summarized': {k: getattr(summarized, k) for k in
+                                      ('aligned', 'unaligned', 'total', 'class_map', 'class_count',
+                                       'fragment_length_frequencies', 'effective_lengths')},
+                       'export': result.export(), 'tpm': tpm, 'steps': quantify.steps})
+        else:
+            assert summarized is None
     finally:
-        dist.barrier()
-        dist.destroy_process_group()
+        ranks.close()
 
 
-def test_two_ranks_equal_one(oracle, native_libs):
+def test_two_ranks_equal_one(oracle, native_libs, tmp_path):
     import torch.multiprocessing as mp
-    from seekmer_amd import parallel, synth
+    index, paths = _sample(str(tmp_path))
     ctx = mp.get_context('spawn')
     queue = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, queue)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), queue)) for r in range(2)]
     for p in procs:
         p.start()
     got = queue.get(timeout=240)
@@ -89,25 +181,31 @@ def test_two_ranks_equal_one(oracle, native_libs):
         p.join(timeout=60)
         assert p.exitcode == 0
 
-    ids, pool, tx_offsets = synth.transcriptome(4, 30)
-    index = oracle.build_index(synth.sequences_of(pool, tx_offsets))
-    bases, offsets = synth.reads(4, pool, tx_offsets, 0, 6001, 75, True, n_threads=1)
+    pairs = oracle.read_fastq_pairs(*paths)
+    bases, offsets = oracle.pack_reads(pairs)
     fld = np.zeros(2000, dtype=np.int64)
-    result = oracle.map_batch(index, bases, offsets, 6001, True, fld)
+    result = oracle.map_batch(index, bases, offsets, N_UNITS, True, fld)
     classes = oracle.Classes()
     classes.update(result)
     offs, targets, counts = classes.export()
-    np.testing.assert_array_equal(got['fld'], fld)
-    np.testing.assert_array_equal(got['merged']['offsets'], offs)      # same classes, same order
-    np.testing.assert_array_equal(got['merged']['targets'], targets)
-    np.testing.assert_array_equal(got['merged']['counts'], counts)
-    assert got['merged']['unaligned'] == classes.unaligned
+    g_offs, g_targets, g_counts, g_first, g_fld = got['export']
+    np.testing.assert_array_equal(g_fld, fld)
+    np.testing.assert_array_equal(g_offs, offs)      # same classes, same (-j1) order
+    np.testing.assert_array_equal(g_targets, targets)
+    np.testing.assert_array_equal(g_counts, counts)
+    assert (np.diff(g_first) > 0).all()
     class_map, class_count = classes.summarize()
+    s = got['summarized']
+    np.testing.assert_array_equal(s['class_map'], class_map)
+    np.testing.assert_array_equal(s['class_count'], class_count)
+    assert (s['aligned'], s['unaligned'], s['total']) == (int(class_count.sum()), classes.unaligned, N_UNITS)
     eff = oracle.effective_lengths(fld, index.lengths)
-    x0 = 1.0 / eff
-    x0 /= x0.sum()
-    x_ref, _ = oracle.em(x0, eff, class_map, class_count, fixed_iters=1)
-    np.testing.assert_allclose(got['x_new'], x_ref, rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(s['effective_lengths'], eff)
+    tpm_ref, iters_ref = oracle.quantify(eff, class_map, class_count)
+    assert got['steps'] == iters_ref
+    mask = tpm_ref > 0
+    np.testing.assert_array_equal(got['tpm'] > 0, mask)
+    np.testing.assert_allclose(got['tpm'][mask], tpm_ref[mask], rtol=1e-9, atol=0)
 
 
 def test_shard_range_covers_everything():
@@ -119,3 +217,15 @@ def test_shard_range_covers_everything():
             assert sum(c for _, c in spans) == n
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1
+
+
+def test_one_rank_needs_no_process_group(monkeypatch):
+    from seekmer_amd import parallel
+    for name in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(name, raising=False)
+    ranks = parallel.Ranks.from_env()
+    assert (ranks.rank, ranks.world, ranks.shard, ranks.dist) == (0, 1, None, None)
+    assert ranks.gather_to_root('x') == ['x']
+    assert parallel.make_comm(ranks, 0) is None
+    ranks.barrier()
+    ranks.close()
