@@ -229,22 +229,35 @@ effective_lengths_kernel(const unsigned long long *__restrict__ fld,
     // histogram has a few hundred occupied bins out of 2000.
     __shared__ double p[MAX_FRAGMENT_LENGTH];
     __shared__ int bin[MAX_FRAGMENT_LENGTH];
-    __shared__ unsigned long long total_s;
+    __shared__ unsigned long long counts[MAX_FRAGMENT_LENGTH];
+    __shared__ unsigned long long part[4];
     __shared__ int n_bins;
-    if (threadIdx.x == 0) {
-        unsigned long long total = 0;
-        for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) total += fld[i];
-        total_s = total;
+    // the histogram once into LDS (coalesced), its total by a block reduction (integers: any order)
+    unsigned long long mine = 0;
+    for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x) {
+        counts[i] = fld[i];
+        mine += counts[i];
     }
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
     __syncthreads();
-    const double total = (double)(long long)total_s;
-    if (threadIdx.x == 0) {
+    const double total = (double)(long long)(part[0] + part[1] + part[2] + part[3]);
+    // wave 0 packs the non-zero bins in bin order (ballot + prefix count per 64 bins)
+    if (threadIdx.x < 64) {
         int n = 0;
-        for (int i = 0; i < MAX_FRAGMENT_LENGTH; ++i) {
-            const double v = (double)(long long)fld[i] / total;
-            if (!(v == 0.0)) { p[n] = v; bin[n] = i; ++n; }
+        for (int first = 0; first < MAX_FRAGMENT_LENGTH; first += 64) {
+            const int i = first + (int)threadIdx.x;
+            const double v = i < MAX_FRAGMENT_LENGTH ? (double)(long long)counts[i] / total : 0.0;
+            const bool keep = i < MAX_FRAGMENT_LENGTH && !(v == 0.0);
+            const unsigned long long kept = __ballot(keep);
+            if (keep) {
+                const int at = n + __popcll(kept & ((1ULL << threadIdx.x) - 1));
+                p[at] = v;
+                bin[at] = i;
+            }
+            n += __popcll(kept);
         }
-        n_bins = n;
+        if (threadIdx.x == 0) n_bins = n;
     }
     __syncthreads();
     const int n = n_bins;

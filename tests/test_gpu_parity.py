@@ -729,16 +729,34 @@ def test_impute_end_to_end(oracle, native_libs, tmp_path):
         assert (np.abs(got[mask] - expected[mask]) / expected[mask]).max() < 1e-4
 
 
-def test_baseline_config2_properties(oracle, native_libs):
+@pytest.fixture(scope='module')
+def t190k(native_libs):
+    """The ~190k-transcript stand-in of BASELINE.json's ENSEMBL index (2 GiB k-mer table), built
+    once for the full-size tests of configs[1], [3] and [4]."""
+    from seekmer_amd import synth, index_builder
+    ids, pool, tx_offsets = synth.transcriptome(1, 20000)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    assert index.kmers.size == 1 << 27 and len(ids) > 150000
+    return ids, pool, tx_offsets, index
+
+
+def _upload(native, array):
+    import ctypes
+    hip = native.hip()
+    pointer = ctypes.c_void_p()
+    native.check(hip.skm_device_malloc(0, array.nbytes, ctypes.byref(pointer)))
+    native.check(hip.skm_device_upload(0, pointer, array.ctypes.data, array.nbytes))
+    return pointer
+
+
+def test_baseline_config2_properties(oracle, native_libs, t190k):
     """BASELINE.json configs[1] at its full size -- the ~190k-transcript stand-in index
     (2 GiB k-mer table) and 10 M 2x100 pairs, where the oracle would need a minute per run --
     through properties that do not need it: totals, first-seen order, the same counter from two
     uneven batches and from a second run (the scheduler is asynchronous, the integers must not
     care), and the device quantification against the numpy one bit for bit."""
-    from seekmer_amd import synth, index_builder, mapper, common, infer
-    ids, pool, tx_offsets = synth.transcriptome(1, 20000)
-    index = index_builder.build_pooled(ids, pool, tx_offsets)
-    assert index.kmers.size == 1 << 27 and len(ids) > 150000
+    from seekmer_amd import synth, mapper, common, infer
+    ids, pool, tx_offsets, index = t190k
     n_units = 10_000_000
     bases, offsets = synth.reads(1, pool, tx_offsets, 0, n_units, 100, True)
     whole = mapper.MapResult(index)
@@ -772,6 +790,94 @@ def test_baseline_config2_properties(oracle, native_libs):
     assert iters_host == iters_dev
     np.testing.assert_array_equal(tpm_host, tpm_dev)
     assert abs(tpm_dev.sum() - 1e6) < 1e-3
+
+
+def test_baseline_config3_properties(native_libs, t190k):
+    """BASELINE.json configs[3] at its full size: 50 M single-end 150 bp reads (`-s`) against
+    the same index, one resident batch.  Every single-ended read is counted in the
+    fragment-length histogram -- unmapped ones at 25 (_mapper.pyx:90-94) -- the
+    table does not depend on how the sample is cut into batches, two runs agree bit for bit, and
+    the device quantification equals the numpy one."""
+    from seekmer_amd import synth, mapper, infer, _native
+    ids, pool, tx_offsets, index = t190k
+    n_units, read_len = 50_000_000, 150
+    bases, offsets = synth.reads(3, pool, tx_offsets, 0, n_units, read_len, False)
+    d_bases, d_offsets = _upload(_native, bases), _upload(_native, offsets)
+    whole = mapper.MapResult(index)
+    whole.map_resident(d_bases, d_offsets, n_units, False, read_len)
+    c, rows, unaligned, total = whole.sizes()
+    offs, targets, counts, first_seen, fld = whole.export()
+    assert total == n_units and counts.sum() + unaligned == n_units
+    assert fld.sum() == n_units and fld[:25].sum() == 0 and fld[25] >= unaligned      # every read counted
+    assert fld[read_len + 1:].sum() == 0                         # a single read spans at most its length
+    assert (np.diff(first_seen) > 0).all() and unaligned < 0.03 * n_units
+    assert (targets >= 0).all() and targets.max() < len(ids) and offs[-1] == rows
+    # the same sample in three uneven resident batches (device pointers into the same buffers)
+    import ctypes
+    split = mapper.MapResult(index)
+    cuts = [0, 11_111_111, 11_111_112, n_units]
+    hip = _native.hip()
+    for k in range(3):
+        lo, hi = cuts[k], cuts[k + 1]
+        sub = np.ascontiguousarray(offsets[lo:hi + 1] - offsets[lo])
+        d_sub = _upload(_native, sub)
+        split.map_resident(ctypes.c_void_p(d_bases.value + int(offsets[lo])), d_sub, hi - lo, False, read_len)
+        _native.check(hip.skm_device_free(0, d_sub))
+    for got, want in zip(split.export(), (offs, targets, counts, first_seen, fld)):
+        np.testing.assert_array_equal(got, want)
+    tpm, iters = infer.quantify_resident(whole, return_iters=True)
+    tpm2, iters2 = infer.quantify_resident(split, return_iters=True)
+    assert iters == iters2 and np.array_equal(tpm, tpm2) and abs(tpm.sum() - 1e6) < 1e-3
+    tpm_host, iters_host = infer.quantify(whole.summarize(), return_iters=True)
+    assert iters_host == iters and np.array_equal(tpm_host, tpm)
+    _native.check(hip.skm_device_free(0, d_bases))
+    _native.check(hip.skm_device_free(0, d_offsets))
+
+
+def test_baseline_config4_properties(native_libs, t190k):
+    """BASELINE.json configs[4] at its full size: 20 M 2x100 bp pairs mapped, then `-b 100` on the
+    resident class table (GPU-side multinomial resampling + EM from the main estimate,
+    seekmer/infer.py:79-82, 108-111).  Bootstrap totals are exact, the draws are reproducible
+    from the seed and differ between replicates, their mean and dispersion follow
+    multinomial(n, count / n) on the populated classes, every replicate is a TPM vector, and the
+    handle holds the observed counts again afterwards.  (EM-on-drawn-counts against the oracle:
+    test_config4_bootstrap_on_a_mapped_table, at a size the oracle handles.)"""
+    from seekmer_amd import synth, mapper, infer, _native
+    ids, pool, tx_offsets, index = t190k
+    n_units, n_boot = 20_000_000, 100
+    bases, offsets = synth.reads(4, pool, tx_offsets, 0, n_units, 100, True)
+    d_bases, d_offsets = _upload(_native, bases), _upload(_native, offsets)
+    result = mapper.MapResult(index)
+    result.map_resident(d_bases, d_offsets, n_units, True, 100)
+    tpm, iters, eff = infer.quantify_resident(result, return_iters=True, return_effective_lengths=True)
+    class_count = result.export()[2].astype('f8')
+    n = class_count.sum()
+    assert n == result.sizes()[3] - result.sizes()[2] and class_count.size > 800_000
+    quant = infer._QuantHandle.from_map_result(result, len(ids))
+    x0 = tpm / tpm.sum()
+    out, counts, its = quant.bootstrap(n_boot, 99, x0, eff, want_counts=True)
+    assert (counts.sum(axis=1) == n).all()                        # totals exact
+    assert len({c.tobytes() for c in counts[:10]}) == 10
+    out2, counts2, its2 = quant.bootstrap(3, 99, x0, eff, want_counts=True)
+    np.testing.assert_array_equal(counts2, counts[:3])            # seeded
+    np.testing.assert_array_equal(out2, out[:3])
+    p = class_count / n
+    mean = counts.mean(axis=0)
+    assert (np.abs(mean - n * p) < 6 * np.sqrt(n * p * (1 - p) / n_boot) + 1).all()
+    big = np.argsort(class_count)[-20000:]                        # the populated classes carry the test
+    _check_multinomial_dispersion(np.concatenate([counts[:, big], (n - counts[:, big].sum(axis=1))[:, None]], axis=1),
+                                  np.concatenate([class_count[big], [n - class_count[big].sum()]]))
+    assert (its > 0).all() and np.isfinite(out).all() and (out >= 0).all()
+    boot_tpm = infer._tpm(out[0].copy())
+    assert abs(boot_tpm.sum() - 1e6) < 1e-3
+    ok = tpm > 10
+    assert np.median(np.abs(boot_tpm[ok] - tpm[ok]) / tpm[ok]) < 0.2   # a resample stays near the estimate
+    x_again, it_again = quant.em(1.0 / eff / (1.0 / eff).sum(), eff)
+    quant.close()
+    assert it_again == iters and np.array_equal(infer._tpm(x_again), tpm)   # observed counts restored
+    hip = _native.hip()
+    _native.check(hip.skm_device_free(0, d_bases))
+    _native.check(hip.skm_device_free(0, d_offsets))
 
 
 @pytest.mark.parametrize('read_len,paired', [(150, False), (251, True), (33, True)])
