@@ -149,7 +149,7 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
         t0 = time.perf_counter()
         for k in range(pieces):
             sub = common.ReadBatch(cut[k + 1] - cut[k], h_bases, h_offsets[2 * cut[k]:2 * cut[k + 1] + 1], True,
-                                   first_unit=cut[k])
+                                   first_unit=cut[k], uniform_len=read_len)
             rm.map_batch_async(sub)
         result.sync()
         t_map = time.perf_counter() - t0
@@ -159,9 +159,10 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
     best = min((from_host() for _ in range(passes + 1)), key=lambda t: t[1])
     out['pcie_inclusive'] = {
         'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
-        'host_bytes': int(n_bytes + offsets.size * 8), 'GBps_over_pcie': (n_bytes + offsets.size * 8) / best[0] / 1e9,
-        'how': '%d pairs in page-locked host arrays (skm_pinned_alloc), %d batches through '
-               'skm_mapper_map_batch_async, then skm_quant_infer; best of %d passes' % (n_units, pieces, passes)}
+        'host_bytes': int(n_bytes), 'GBps_over_pcie': n_bytes / best[0] / 1e9,
+        'how': '%d pairs in page-locked host arrays (skm_pinned_alloc), %d batches of equal-length reads through '
+               'skm_mapper_map_batch_uniform_async (no offsets over the link), then skm_quant_infer; best of %d passes'
+               % (n_units, pieces, passes)}
     classes_host = result.sizes()
     hip.skm_pinned_free(p_bases)
     hip.skm_pinned_free(p_offsets)

@@ -124,6 +124,11 @@ int skm_mapper_map_batch(skm_mapper *mapper, const char *bases,
 int skm_mapper_map_batch_async(skm_mapper *mapper, const char *bases,
                                const int64_t *offsets, int64_t n_units, int paired,
                                int64_t first_unit);
+/* A batch whose reads all have the same length (raw Illumina reads): `bases` holds them back to
+ * back, read r = [r * read_len, (r + 1) * read_len); no offsets cross PCIe (8 bytes per read, 7 %
+ * of a 2x100 bp batch), the device makes them.  The fixed-stride form of SURVEY.md 8(b).2. */
+int skm_mapper_map_batch_uniform_async(skm_mapper *mapper, const char *bases, int32_t read_len,
+                                       int64_t n_units, int paired, int64_t first_unit);
 int skm_mapper_sync(skm_mapper *mapper);
 /* Same with the batch already resident in HBM (device pointers; max_read_len
  * must bound every read length). */
@@ -267,6 +272,9 @@ int skm_fastq_set_parallel(skm_fastq *reader, int n_threads, int *enabled);
  * -- its first unit is k * batch_units of the whole sample. */
 int skm_fastq_set_shard(skm_fastq *reader, int rank, int world);
 int skm_fastq_batch_index(const skm_fastq *reader, int64_t *index);
+/* the common length of the reads of the batch handed out last, or -1 when they differ
+ * (skm_mapper_map_batch_uniform_async takes a batch of equal-length reads without offsets) */
+int skm_fastq_batch_read_length(const skm_fastq *reader, int64_t *read_len);
 /* next batch: *n_units = 0 at end.  Buffers are owned by the reader and stay
  * valid until the next call.  names: '\n'-separated. */
 int skm_fastq_next(skm_fastq *reader, int64_t *n_units, const char **bases,

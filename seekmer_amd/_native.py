@@ -52,6 +52,8 @@ HIP_SYMBOLS = {
                                             ctypes.c_int]),
     'skm_mapper_map_batch_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64p, c_i64,
                                                   ctypes.c_int, c_i64]),
+    'skm_mapper_map_batch_uniform_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, c_i64,
+                                                          ctypes.c_int, c_i64]),
     'skm_mapper_sync': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_map_batch_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, c_i64, ctypes.c_int,
@@ -101,6 +103,7 @@ HOST_SYMBOLS = {
     'skm_fastq_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_set_parallel': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'skm_fastq_set_shard': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'skm_fastq_batch_read_length': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_fastq_batch_index': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_fastq_next': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_void_pp, c_void_pp, c_void_pp,
                                       c_void_pp]),

@@ -248,10 +248,12 @@ class ReadBatch:
     to back) and `offsets` (int64[n_reads + 1]).  Unpacks like the reference's
     (count, names, reads) triple, so code written against the feeders works."""
 
-    __slots__ = ('count', 'bases', 'offsets', 'paired', '_names', '_name_offsets', 'first_unit')
+    __slots__ = ('count', 'bases', 'offsets', 'paired', '_names', '_name_offsets', 'first_unit', 'uniform_len')
 
-    def __init__(self, count, bases, offsets, paired, names=None, name_offsets=None, first_unit=None):
+    def __init__(self, count, bases, offsets, paired, names=None, name_offsets=None, first_unit=None,
+                 uniform_len=None):
         self.first_unit = first_unit          # index of the batch's first unit in its sample, if known
+        self.uniform_len = uniform_len        # the length every read of the batch has, if they all agree
         self.count = int(count)
         self.bases = bases
         self.offsets = offsets
@@ -422,8 +424,12 @@ class NativeReadFeeder:
                 name_bytes = view(p_names, max(int(name_offsets[-1]), 1), ctypes.c_uint8, numpy.uint8)
                 _native.check_host(host.skm_fastq_batch_index(reader.handle, ctypes.byref(k)),
                                    'skm_fastq_batch_index')
+                same = ctypes.c_int64(-1)
+                _native.check_host(host.skm_fastq_batch_read_length(reader.handle, ctypes.byref(same)),
+                                   'skm_fastq_batch_read_length')
                 batch = ReadBatch(n.value, bases, offsets, self.paired, name_bytes, name_offsets,
-                                  first_unit=k.value * self.batch_units)
+                                  first_unit=k.value * self.batch_units,
+                                  uniform_len=same.value if same.value >= 0 else None)
                 yield batch
                 del batch, owner, bases, offsets, name_bytes, name_offsets, view
         finally:

@@ -126,7 +126,6 @@ struct skm_mapper {
     DBuf<int64_t> offsets;
     DBuf<uint32_t> records;
     DBuf<int32_t> workspace;
-    DBuf<char> mate1;
     DBuf<int32_t> unit_begin, unit_end, rec_unit;
     DBuf<Coord> unit_anchor;
     DBuf<int64_t> unit_slot;
@@ -651,7 +650,6 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     // per context: mask extension words (live + staging, two mates) for slices > 64 targets
     const int64_t ext_words = std::max<int64_t>(0, (ix->d.max_target_count + 63) / 64 - 1);
     SKM_TRY(m->workspace.ensure((size_t)(blocks * CONTEXTS * 4 * ext_words * 2 + 16)));
-    SKM_TRY(m->mate1.ensure((size_t)(blocks * CONTEXTS) * 64 + 64));
     m->grid_blocks = (int)blocks;
     {   // the kernel addresses a block's records with 32-bit byte offsets
         const int64_t per_block = (n_units + blocks - 1) / blocks;
@@ -669,7 +667,6 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     b.record_words = record_words;
     b.paired = paired;
     b.workspace = m->workspace.p;
-    b.mate1 = m->mate1.p;
     b.unit_begin = m->unit_begin.p;
     b.unit_end = m->unit_end.p;
     b.unit_anchor = m->unit_anchor.p;
@@ -800,7 +797,7 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->slots.release(); m->arena.release(); m->class_list.release();
     m->counters.release();
     m->error.release(); m->bases.release(); m->offsets.release(); m->records.release();
-    m->workspace.release(); m->mate1.release(); m->unit_begin.release(); m->unit_end.release();
+    m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
     m->rec_unit.release(); m->unit_anchor.release(); m->rec_tuple.release();
     m->unit_slot.release(); m->rec_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
@@ -887,15 +884,18 @@ int wait_jobs(skm_mapper *m, uint64_t ticket, bool consume)
     return SKM_OK;
 }
 
-int submit_batch(skm_mapper *m, const char *bases, const int64_t *offsets, int64_t n_units, int paired,
-                 int64_t first_unit, uint64_t *ticket_out)
+// offsets == nullptr: every read is `uniform_len` bases long (the offsets are then made on the device)
+int submit_batch(skm_mapper *m, const char *bases, const int64_t *offsets, int64_t uniform_len, int64_t n_units,
+                 int paired, int64_t first_unit, uint64_t *ticket_out)
 {
-    if (!m || !offsets || n_units < 0) return fail(SKM_ERR_ARG, "bad argument");
+    if (!m || n_units < 0 || (!offsets && uniform_len < 0)) return fail(SKM_ERR_ARG, "bad argument");
     if (n_units > 0 && !bases) return fail(SKM_ERR_ARG, "bases is NULL");
     if (n_units >= (1LL << 31)) return fail(SKM_ERR_ARG, "more than 2^31 - 1 units in one batch");
+    if (!offsets && uniform_len > (1 << 20)) return fail(SKM_ERR_ARG, "read longer than 2^20 bases");
     SKM_TRY(set_device(m->ix->device));
     const int64_t n_reads = paired ? 2 * n_units : n_units;
-    const int64_t n_bytes = offsets[n_reads] - offsets[0];
+    const int64_t first_byte = offsets ? offsets[0] : 0;
+    const int64_t n_bytes = offsets ? offsets[n_reads] - offsets[0] : n_reads * uniform_len;
     if (n_bytes < 0) return fail(SKM_ERR_ARG, "offsets are not monotone");
     // a free lane (at most N_LANES batches are in HBM at a time: one being mapped, others copied)
     int li = -1;
@@ -922,15 +922,18 @@ int submit_batch(skm_mapper *m, const char *bases, const int64_t *offsets, int64
     // pinned sources go over the link at full rate and asynchronously; pageable ones are staged
     // by the runtime.  Either way the source is free again when this call returns.
     if (n_bytes)
-        HIP_TRY(hipMemcpyAsync(lane.bases.p, bases + offsets[0], (size_t)n_bytes, hipMemcpyHostToDevice, lane.stream));
-    HIP_TRY(hipMemcpyAsync(lane.offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
-                           lane.stream));
+        HIP_TRY(hipMemcpyAsync(lane.bases.p, bases + first_byte, (size_t)n_bytes, hipMemcpyHostToDevice, lane.stream));
+    if (offsets)
+        HIP_TRY(hipMemcpyAsync(lane.offsets.p, offsets, (size_t)(n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                               lane.stream));
+    else
+        launch_offsets_uniform(lane.offsets.p, n_reads, uniform_len, lane.stream);
     HIP_TRY(hipStreamSynchronize(lane.stream));
     uint64_t ticket;
     {
         std::lock_guard<std::mutex> hold(m->q_mu);
         ticket = m->next_ticket++;
-        m->jobs.push_back(skm_mapper::Job{li, n_units, paired, offsets[0], first_unit, ticket});
+        m->jobs.push_back(skm_mapper::Job{li, n_units, paired, first_byte, first_unit, ticket});
     }
     release.dismiss();
     m->q_cv.notify_one();
@@ -943,7 +946,15 @@ int submit_batch(skm_mapper *m, const char *bases, const int64_t *offsets, int64
 extern "C" int skm_mapper_map_batch_async(skm_mapper *m, const char *bases, const int64_t *offsets,
                                           int64_t n_units, int paired, int64_t first_unit)
 {
-    return submit_batch(m, bases, offsets, n_units, paired, first_unit, nullptr);
+    if (!offsets) return fail(SKM_ERR_ARG, "offsets is NULL");
+    return submit_batch(m, bases, offsets, -1, n_units, paired, first_unit, nullptr);
+}
+
+extern "C" int skm_mapper_map_batch_uniform_async(skm_mapper *m, const char *bases, int32_t read_len,
+                                                  int64_t n_units, int paired, int64_t first_unit)
+{
+    if (read_len < 0) return fail(SKM_ERR_ARG, "negative read length");
+    return submit_batch(m, bases, nullptr, read_len, n_units, paired, first_unit, nullptr);
 }
 
 extern "C" int skm_mapper_sync(skm_mapper *m)
@@ -956,7 +967,8 @@ extern "C" int skm_mapper_map_batch(skm_mapper *m, const char *bases, const int6
                                     int64_t n_units, int paired)
 {
     uint64_t ticket = 0;
-    SKM_TRY(submit_batch(m, bases, offsets, n_units, paired, -1, &ticket));
+    if (!offsets) return fail(SKM_ERR_ARG, "offsets is NULL");
+    SKM_TRY(submit_batch(m, bases, offsets, -1, n_units, paired, -1, &ticket));
     return wait_jobs(m, ticket, true);
 }
 

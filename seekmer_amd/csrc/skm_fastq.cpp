@@ -142,6 +142,13 @@ struct skm_fastq_slab {
     Buf<char> bases, names;
     Buf<int64_t> offsets, name_offsets;
     int64_t units = 0;
+    int64_t read_len = -2;                     // -2 no read yet, >= 0 every read so far this long, -1 ragged
+    void add_read(const char *p, size_t len)
+    {
+        bases.append(p, len);
+        offsets.push((int64_t)bases.n);
+        read_len = read_len == -2 ? (int64_t)len : (read_len == (int64_t)len ? read_len : -1);
+    }
     void use(alloc_fn al, free_fn fr)
     {
         if (bases.al == al && bases.fr == fr) return;
@@ -154,6 +161,7 @@ struct skm_fastq_slab {
         bases.clear(); names.clear(); offsets.clear(); name_offsets.clear();
         offsets.push(0); name_offsets.push(0);
         units = 0;
+        read_len = -2;
     }
     bool failed() const { return bases.failed || names.failed || offsets.failed || name_offsets.failed; }
     ~skm_fastq_slab() { bases.release(); names.release(); offsets.release(); name_offsets.release(); }
@@ -349,16 +357,14 @@ struct skm_fastq {
             out->name_offsets.push((int64_t)out->names.n);
             line(a, pa, p, len);                                  // i & 3 == 1: the bases
             strip(p, len);
-            out->bases.append(p, len);
-            out->offsets.push((int64_t)out->bases.n);
+            out->add_read(p, len);
             line(a, pa, p, len);
             line(a, pa, p, len);
             if (b) {
                 line(*b, pb, p, len);
                 line(*b, pb, p, len);
                 strip(p, len);
-                out->bases.append(p, len);
-                out->offsets.push((int64_t)out->bases.n);
+                out->add_read(p, len);
                 line(*b, pb, p, len);
                 line(*b, pb, p, len);
             }
@@ -590,12 +596,10 @@ extern "C" int skm_fastq_next(skm_fastq *q, int64_t *n_units, const char **bases
             q->held++;
         } else if (phase == 1) {
             strip(l1, n1);
-            b->bases.append(l1, n1);
-            b->offsets.push((int64_t)b->bases.n);
+            b->add_read(l1, n1);
             if (q->paired) {
                 strip(l2, n2);
-                b->bases.append(l2, n2);
-                b->offsets.push((int64_t)b->bases.n);
+                b->add_read(l2, n2);
             }
             if (q->held >= q->batch_units) full = true;          // len(read_names) >= BUFFER_SIZE
         }
@@ -625,6 +629,13 @@ extern "C" int skm_fastq_set_shard(skm_fastq *q, int rank, int world)
     if (q->open || q->finished || q->next_path || !q->workers.empty() || q->next_deliver) return SKM_ERR_STATE;
     q->shard_rank = rank;
     q->shard_world = world;
+    return SKM_OK;
+}
+
+extern "C" int skm_fastq_batch_read_length(const skm_fastq *q, int64_t *read_len)
+{
+    if (!q || !read_len) return SKM_ERR_ARG;
+    *read_len = q->cur && q->cur->read_len >= 0 ? q->cur->read_len : -1;
     return SKM_OK;
 }
 

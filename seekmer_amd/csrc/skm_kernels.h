@@ -13,7 +13,6 @@ struct MapBatch {
     int32_t record_words;         // u32 words per record, a multiple of 16 (64 bytes)
     int32_t paired;
     int32_t *workspace;           // per-context mask extension words (slices > 64 targets)
-    void *mate1;                  // per-context parking slot of the mate-1 span and set (48 B)
     // Results.  Units finish out of order, so a wave writes what it finishes as RECORDS: 64
     // finished units take 64 consecutive places of their block's own range (block b owns
     // records [b * per_block, ...) like it owns those units), and the three stores of a wave
@@ -52,6 +51,7 @@ void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_r
 // out[0] = longest read, out[1] = places where the offsets step backwards; then offsets -= base
 void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,
                          hipStream_t stream);
+void launch_offsets_uniform(int64_t *offsets, int64_t n_reads, int64_t read_len, hipStream_t stream);
 void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream);
 // build the bucket table from the reference table and check the reference probe (see DevBucket);
 // report: [0] placed [1] placed outside the home bucket [2] k-mers met twice [3] slots the

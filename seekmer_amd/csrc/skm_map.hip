@@ -142,6 +142,13 @@ offsets_scan_kernel(int64_t *offsets, int64_t n_reads, int64_t base, unsigned lo
         if (descents) atomicAdd(&out[1], descents);
     }
 }
+// offsets of a batch whose reads all have the same length: never sent over PCIe
+__global__ void __launch_bounds__(256)
+offsets_uniform_kernel(int64_t *offsets, int64_t n, int64_t read_len)
+{
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n;
+         r += (int64_t)gridDim.x * blockDim.x) offsets[r] = r * read_len;
+}
 __global__ void __launch_bounds__(256)
 offsets_rebase_kernel(int64_t *offsets, int64_t n, int64_t base)
 {
@@ -657,17 +664,14 @@ enum : int { ST_IDLE = 0, ST_NEW,
              N_LEFT, N_RIGHT,                          // want an 8-base alignment step
              N_RIGHT_ENTER, N_AFTER, N_MATE_DONE,      // cheap transitions
              ST_UNIT_DONE,                             // want emission
-             Y_SCAN };                                 // want a run of lookups
+             Y_SCAN,                                   // want a run of lookups
+             ST_HALF };                                // a mate that is done and waits for the other one
 enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_ACTIONS };
 constexpr int SCAN_ROUNDS = 4;
 
 constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
 
-struct alignas(64) Mate1 {            // span and target set of mate 1, parked in HBM: one sector per slot
-    int32_t begin, end, anchor_entry, anchor_offset, n, len, set_start, set_length_fwd;
-    uint64_t word0;
-};
 constexpr int FLD_WINDOW = 512;       // fragment lengths below this are counted in LDS
 
 __device__ __forceinline__ int action_of(int state)
@@ -715,11 +719,20 @@ map_units_kernel(DevIndex ix, MapBatch b)
     // one MPMC ring per action: entry = context | 0x8000 once written, 0 while empty
     __shared__ uint16_t ring[N_ACTIONS][NCTX];
     __shared__ uint32_t q_head[N_ACTIONS], q_tail[N_ACTIONS], next_unit, done_units, busy, stalled;
+    // Paired batches: the two mates of a unit are mapped SIDE BY SIDE by the contexts 2p (mate 1)
+    // and 2p + 1 (mate 2) of pair slot p -- map_read_pair maps them independently and only then
+    // intersects (_mapper.pyx:119-128).  The mate that finishes first stays in its context
+    // (ST_HALF); the one that finishes second takes the unit to the emission, which reads both
+    // contexts.  pair_done[p] counts the finished mates of the slot.  (Mapping the mates one after
+    // the other in one context meant parking mate 1's span and set in HBM: a sector written and
+    // a sector read back per pair.)
+    __shared__ uint32_t pair_done[NCTX / 2];
 
     for (int i = threadIdx.x; i < FLD_WINDOW; i += blockDim.x) fld_lds[i] = 0;
     for (int i = threadIdx.x; i < N_ACTIONS * NCTX; i += blockDim.x) (&ring[0][0])[i] = 0;
     if (threadIdx.x < N_ACTIONS) { q_head[threadIdx.x] = 0; q_tail[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { next_unit = 0; done_units = 0; busy = 0; stalled = 0; }
+    for (int i = threadIdx.x; i < NCTX / 2; i += blockDim.x) pair_done[i] = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -731,7 +744,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
     const int ext_words = max(0, (ix.max_target_count + 63) / 64 - 1);
     uint64_t *const ws_block = reinterpret_cast<uint64_t *>(b.workspace)
                                + (size_t)blockIdx.x * NCTX * 4 * (size_t)ext_words;
-    Mate1 *const mate1_block = reinterpret_cast<Mate1 *>(b.mate1) + (size_t)blockIdx.x * NCTX;
     // the block's records, addressed with 32-bit byte offsets (the host checks the range fits)
     const uint32_t record_bytes = (uint32_t)b.record_words << 2;
     const char *const block_records = reinterpret_cast<const char *>(b.records)
@@ -746,13 +758,16 @@ map_units_kernel(DevIndex ix, MapBatch b)
     for (int i = 0; i < 2 + N_ACTIONS + 6; ++i) cyc[i] = 0;
     unsigned long long t_mark = STATS ? clock64() : 0;
 
-    // seed: every context takes a unit and queues up for A_START
-    for (int c = threadIdx.x; c < NCTX; c += blockDim.x) {
+    // seed: every context (pair of contexts) takes a unit and queues up for A_START
+    const int slot_width = b.paired ? 2 : 1;
+    for (int c = slot_width * (int)threadIdx.x; c + slot_width <= NCTX; c += slot_width * (int)blockDim.x) {
         const uint32_t k = atomicAdd(&next_unit, 1u);
         if ((int64_t)k < block_units) {
-            c_unit[c] = (int32_t)k;
-            c_state[c] = ST_NEW;
-            ring[A_START][atomicAdd(&q_tail[A_START], 1u) % NCTX] = (uint16_t)(c | 0x8000);
+            for (int m = 0; m < slot_width; ++m) {
+                c_unit[c + m] = (int32_t)k;
+                c_state[c + m] = ST_NEW;
+                ring[A_START][atomicAdd(&q_tail[A_START], 1u) % NCTX] = (uint16_t)((c + m) | 0x8000);
+            }
         }
     }
     __syncthreads();
@@ -810,11 +825,13 @@ map_units_kernel(DevIndex ix, MapBatch b)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         int next_action = -1;                             // queue the context goes to afterwards
+        int partner = -1;                                 // (emission of a pair: the other context starts over too)
         {
             const unsigned long long t_action = STATS ? clock64() : 0;
             // load the context
             int word = valid ? c_state[c] : ST_IDLE;
-            int state = word & 0xff, mate = (word >> 8) & 1, attempt = (word >> 9) & 1;
+            int state = word & 0xff, attempt = (word >> 9) & 1;
+            const int mate = b.paired ? (c & 1) : 0;
             const int64_t u = block_first + c_unit[c];
             Span span{c_begin[c], c_end[c], Coord{c_aentry[c], c_aoffset[c]}, (int32_t)((uint32_t)word >> 10)};
             uint32_t look = c_look[c];
@@ -823,8 +840,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
             int scan_i = (int)(scan_word & 0xffffffu);
             uint32_t head_acgt = scan_word >> 24, tail_acgt = len_word >> 24;
             uint64_t kmer = ((uint64_t)c_kmer_hi[c] << 32) | c_kmer_lo[c];
-            uint64_t *const ext1 = ws_block + (size_t)c * 4 * (size_t)ext_words;
-            uint64_t *const ext2 = ext1 + 2 * (size_t)ext_words;
+            uint64_t *const ext1 = ws_block + (size_t)(b.paired ? (c & ~1) : c) * 4 * (size_t)ext_words;
+            uint64_t *const ext2 = ext1 + 2 * (size_t)ext_words;       // (mate 2 of the pair slot)
             TSet set{c_tstart[c], c_tlen[c] >> 1, (c_tlen[c] & 1) != 0,
                      ((uint64_t)c_mask_hi[c] << 32) | c_mask_lo[c], mate ? ext2 : ext1, ext_words};
             const uint32_t first_read = b.paired ? 2u * (uint32_t)c_unit[c] : (uint32_t)c_unit[c];
@@ -843,9 +860,9 @@ map_units_kernel(DevIndex ix, MapBatch b)
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
             if (valid && action == A_START) {
-                rv = read_view(block_records, b.record_words, b.words_per_read, first_read);
-                mate = 0;
+                rv = read_view(block_records, b.record_words, b.words_per_read, first_read + (uint32_t)mate);
                 attempt = 0;
+                set.ext = mate ? ext2 : ext1;
                 set.start = 0; set.length = 0; set.word0 = 0;   // (a context starts with whatever LDS held)
                 span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
                 if (STATS) { read_bases += rv.len; n_reads++; }
@@ -1068,13 +1085,17 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 rec_base = __shfl(rec_base, 0, 64);
                 if (valid) {
                     if (b.paired) {
-                        // map_read_pair, _mapper.pyx:129-144 (span/set = mate 2, parked = mate 1)
-                        const Mate1 m1 = mate1_block[c];
-                        Span s1{m1.begin, m1.end, Coord{m1.anchor_entry, m1.anchor_offset}, m1.n};
-                        TSet set1{m1.set_start, m1.set_length_fwd >> 1, (m1.set_length_fwd & 1) != 0,
-                                  m1.word0, ext1, ext_words};
+                        // map_read_pair, _mapper.pyx:129-144: both mates' contexts of the pair slot
+                        const int c1 = c & ~1, c2 = c | 1;
+                        const int word1 = c_state[c1], word2 = c_state[c2];
+                        Span s1{c_begin[c1], c_end[c1], Coord{c_aentry[c1], c_aoffset[c1]}, (int32_t)((uint32_t)word1 >> 10)};
+                        TSet set1{c_tstart[c1], c_tlen[c1] >> 1, (c_tlen[c1] & 1) != 0,
+                                  ((uint64_t)c_mask_hi[c1] << 32) | c_mask_lo[c1], ext1, ext_words};
+                        span = Span{c_begin[c2], c_end[c2], Coord{c_aentry[c2], c_aoffset[c2]}, (int32_t)((uint32_t)word2 >> 10)};
+                        set = TSet{c_tstart[c2], c_tlen[c2] >> 1, (c_tlen[c2] & 1) != 0,
+                                   ((uint64_t)c_mask_hi[c2] << 32) | c_mask_lo[c2], ext2, ext_words};
+                        const int len1 = (int)((uint32_t)c_len[c1] & 0xffffffu), len2 = (int)((uint32_t)c_len[c2] & 0xffffffu);
                         const Span s2 = span;
-                        if (STATS) asm volatile("" ::"v"(m1.word0));
                         phase(0);
                         if (!intersect<COUNT>(ix, set1, s1, set, s2)) {
                             s1.n = 0;
@@ -1086,7 +1107,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         } else {
                             int interval = s2.anchor.offset - s1.anchor.offset;
                             if (s1.anchor.entry < 0) interval = -interval;
-                            s1.end = (m1.len - K) + interval + (rv.len - K) - s2.begin;
+                            s1.end = (len1 - K) + interval + (len2 - K) - s2.begin;
                         }
                         span = s1;
                         set = set1;
@@ -1169,7 +1190,15 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 base = __shfl(base, 0, 64);
                 if (valid) {
                     const uint32_t k = base + __popcll(finished & ((1ULL << lane) - 1));
-                    if ((int64_t)k < block_units) {
+                    const bool more = (int64_t)k < block_units;
+                    if (b.paired) {                       // both contexts of the pair slot start over
+                        const int c1 = c & ~1, c2 = c | 1;
+                        c_unit[c1] = (int32_t)k; c_unit[c2] = (int32_t)k;
+                        c_state[c1] = more ? ST_NEW : ST_IDLE;
+                        c_state[c2] = more ? ST_NEW : ST_IDLE;
+                        pair_done[c >> 1] = 0;
+                        if (more) { next_action = A_START; partner = c ^ 1; }
+                    } else if (more) {
                         c_unit[c] = (int32_t)k;
                         c_state[c] = ST_NEW;
                         next_action = A_START;
@@ -1209,36 +1238,14 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         if (scan_i < rv.len) look = read_half(rv, scan_i >> 4);
                         state = Y_FIRST;
                     }
-                } else if (b.paired && mate == 0) {           // N_MATE_DONE: on to mate 2
-                    mate1_block[c] = Mate1{span.begin, span.end, span.anchor.entry, span.anchor.offset,
-                                           span.n, rv.len, set.start, (set.length << 1) | (set.forward ? 1 : 0),
-                                           set.word0};
-                    set.ext = ext2;
-                    set.length = 0;
-                    set.word0 = 0;
-                    mate = 1;
-                    attempt = 0;
-                    rv = read_view(block_records, b.record_words, b.words_per_read, first_read + 1u);
-                    span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
-                    if (STATS) { read_bases += rv.len; n_reads++; }
-                    if (rv.len >= K) {
-                        kmer = read_kmer(rv, 0);
-                        scan_i = K;
-                        look = read_half(rv, scan_i >> 4);
-                        keep_edges();
-                        state = Y_FIRST;
-                    } else {
-                        state = ST_UNIT_DONE;                 // mate 2 shorter than k: unmapped
-                    }
-                } else {
-                    state = ST_UNIT_DONE;
+                } else {                                      // N_MATE_DONE
+                    state = b.paired ? ST_HALF : ST_UNIT_DONE;
                 }
             }
 
             // store the context
             if (valid && action != A_EMIT) {
-                c_state[c] = (int32_t)((uint32_t)state | ((uint32_t)mate << 8) | ((uint32_t)attempt << 9)
-                                       | ((uint32_t)span.n << 10));
+                c_state[c] = (int32_t)((uint32_t)state | ((uint32_t)attempt << 9) | ((uint32_t)span.n << 10));
                 c_begin[c] = span.begin;
                 c_end[c] = span.end;
                 c_aentry[c] = span.anchor.entry;
@@ -1253,7 +1260,16 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 c_tlen[c] = (set.length << 1) | (set.forward ? 1 : 0);
                 c_mask_lo[c] = (uint32_t)set.word0;
                 c_mask_hi[c] = (uint32_t)(set.word0 >> 32);
-                next_action = action_of(state);
+                if (state == ST_HALF) {
+                    // this mate is done and its context complete: whoever finds the other mate done
+                    // already takes the unit to the emission, the first one just stays put
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    const uint32_t before = atomicAdd(&pair_done[c >> 1], 1u);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    next_action = before == 1u ? A_EMIT : -1;
+                } else {
+                    next_action = action_of(state);
+                }
             }
             if (STATS) cyc[2 + action] += clock64() - t_action;
         }
@@ -1272,6 +1288,22 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 while (*slot != 0 && ++spins < (1u << 24)) { }   // (a reader that reserved it is about to clear it)
                 if (*slot != 0) stalled = 1;
                 *slot = (uint16_t)(c | 0x8000);
+            }
+        }
+        {   // the other context of a pair slot that starts over
+            const unsigned long long going = __ballot(partner >= 0);
+            if (going) {
+                const int leader = __builtin_ctzll(going);
+                uint32_t pos = 0;
+                if (lane == leader) pos = atomicAdd(&q_tail[A_START], (uint32_t)__popcll(going));
+                pos = __shfl(pos, leader, 64);
+                if (partner >= 0) {
+                    volatile uint16_t *slot = &ring[A_START][(pos + __popcll(going & ((1ULL << lane) - 1))) % NCTX];
+                    uint32_t spins = 0;
+                    while (*slot != 0 && ++spins < (1u << 24)) { }
+                    if (*slot != 0) stalled = 1;
+                    *slot = (uint16_t)(partner | 0x8000);
+                }
             }
         }
         if (lane == 0) atomicSub(&busy, 1u);
@@ -1327,6 +1359,14 @@ void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsign
     if (base != 0)
         hipLaunchKernelGGL(offsets_rebase_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offsets,
                            n_reads + 1, base);
+}
+
+void launch_offsets_uniform(int64_t *offsets, int64_t n_reads, int64_t read_len, hipStream_t stream)
+{
+    int64_t blocks = (n_reads + 1 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(offsets_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offsets, n_reads + 1,
+                       read_len);
 }
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,

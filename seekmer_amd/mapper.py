@@ -289,10 +289,16 @@ class ReadMapper:
         (``batch.first_unit``) keeps the -j1 class order whatever the submission order."""
         hip = _native.hip()
         first_unit = getattr(batch, 'first_unit', None)
+        first_unit = -1 if first_unit is None else int(first_unit)
+        uniform = getattr(batch, 'uniform_len', None)
+        if uniform is not None and batch.count:       # equal-length reads: the offsets stay on the host
+            _native.check(hip.skm_mapper_map_batch_uniform_async(
+                self.map_result._handle, batch.bases.ctypes.data + int(batch.offsets[0]), int(uniform),
+                batch.count, int(batch.paired), first_unit))
+            return
         _native.check(hip.skm_mapper_map_batch_async(
             self.map_result._handle, batch.bases.ctypes.data,
-            _native.ptr(batch.offsets, _native.c_i64p), batch.count, int(batch.paired),
-            -1 if first_unit is None else int(first_unit)))
+            _native.ptr(batch.offsets, _native.c_i64p), batch.count, int(batch.paired), first_unit))
 
     def last_batch(self, n_units):
         """(begin, end, anchor_entry, anchor_offset, counts, signed entries); the spans need a

@@ -1033,6 +1033,14 @@ def test_async_batches_from_host_and_from_fastq(oracle, native_libs, tmp_path):
         rm.map_batch_async(piece)
     one.sync()
     same(one)
+    # equal-length reads: the fixed-stride form (offsets never cross PCIe)
+    one.reset()
+    for piece in pieces:
+        piece.uniform_len = read_len
+        rm.map_batch_async(piece)
+    same(one)
+    for piece in pieces:
+        piece.uniform_len = None
 
     many = mapper.MapResult(index)
     order = [3, 0, 4, 2, 1]
