@@ -342,8 +342,8 @@ def main():
             if comm:
                 _native.check(hip.skm_quant_set_comm(quant.handle, comm))
             x0 = tpm / tpm.sum()
-            out, _, it = quant.bootstrap(bootstraps, args.seed, x0, eff)
-            state['boot_tpm'] = [infer._tpm(row) for row in out]
+            out, _, it = quant.bootstrap(bootstraps, args.seed, x0, eff, tpm=True)    # TPM vectors, as run() keeps them
+            state['boot_tpm'] = out
             quant.close()
             state['boot_s'] += time.perf_counter() - t_b
             state['boot_iters'] += int(it.sum())

@@ -213,6 +213,13 @@ int skm_quant_bootstrap(skm_quant *quant, int64_t n_boot, uint64_t seed,
                         const double *x0, const double *l, double rel_tol,
                         double x_floor, int64_t max_iters, double *out,
                         int64_t *counts_out, int64_t *iters_out);
+/* The same with every replicate returned as the TPM vector quantify() makes of it
+ * (seekmer/infer.py:127-129: x /= x.sum() / 1e6; x[x < 0.001] = 0; again), numpy's summation
+ * order restated on the device -- what run() appends to its bootstrap list (infer.py:79-82). */
+int skm_quant_bootstrap_tpm(skm_quant *quant, int64_t n_boot, uint64_t seed,
+                            const double *x0, const double *l, double rel_tol,
+                            double x_floor, int64_t max_iters, double *out,
+                            int64_t *iters_out);
 /* EM with externally supplied class counts (parity of the bootstrap EM leg). */
 int skm_quant_set_counts(skm_quant *quant, const double *class_counts);
 /* timing[0]=EM kernel ns total [1]=iterations [2]=launches */

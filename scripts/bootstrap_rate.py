@@ -46,6 +46,16 @@ def main():
     t_main = time.perf_counter() - t0
     print('summarize (export of %d classes) %.1f ms; main quantify %.1f ms (%d EM steps)'
           % (summarized.class_count.size, t_sum * 1e3, t_main * 1e3, iters), flush=True)
+    quant = infer._QuantHandle.from_map_result(result, len(ids))
+    eff = summarized.effective_lengths.astype('f8')
+    x0 = main_tpm / main_tpm.sum()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        out, _, its = quant.bootstrap(args.boot, 7, x0, eff)
+        dt = time.perf_counter() - t0
+        print('native call alone: %d bootstraps in %.1f ms = %.2f ms each (%d EM steps in all)'
+              % (args.boot, dt * 1e3, dt * 1e3 / args.boot, int(its.sum())), flush=True)
+    quant.close()
     for rep in range(2):
         t0 = time.perf_counter()
         boots = infer.bootstrap_quantify(summarized, main_tpm, args.boot, seed=7)

@@ -187,7 +187,15 @@ struct skm_quant {
     DBuf<double> cls_count, cls_count_saved, inner, row_sum;
     DBuf<double> eff_len, x0, x1, acc, part_max;
     DBuf<unsigned int> part_flags;
-    DBuf<unsigned long long> ctl, cum, draw;
+    DBuf<unsigned long long> ctl, cum;
+    DBuf<unsigned int> tile_total;            // scratch of the tiled multinomial draw
+    DBuf<double> x_start, boot_out;           // bootstrap: the common start vector, the replicates' results
+    // working set of the batched EM (skm_em_batch.hip): eight bootstrap replicates side by side
+    struct Batch {
+        DBuf<double> cls_count, inner, row_sum, x0, x1, part_max;
+        DBuf<unsigned int> part_flags;
+        DBuf<unsigned long long> ctl;
+    } batch;
     double n_total = 0;
     bool n_total_reduced = false;             // n_total already is the sum over all ranks
     // RCCL communicator (borrowed from an skm_comm), loaded lazily
@@ -1391,7 +1399,7 @@ EmProblem em_problem(skm_quant *q, double rel_tol, double x_floor, int64_t max_i
 
 // runs the EM from the abundance already in q->x0; result left in x[iters & 1]
 int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int64_t fixed_iters,
-           int64_t *iters_out)
+           int64_t *iters_out, int64_t chunk_steps = 16)
 {
     // n = class_count.sum() over ALL ranks (infer.py:152)
     double n_total = q->n_total;
@@ -1405,7 +1413,7 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     p.n_total = n_total;
     HIP_TRY(hipMemsetAsync(q->ctl.p, 0, 16 * 8, q->stream));
     int64_t k = 0;
-    const int64_t chunk = fixed_iters > 0 ? std::min<int64_t>(fixed_iters, 16) : 16;
+    const int64_t chunk = fixed_iters > 0 ? std::min<int64_t>(fixed_iters, chunk_steps) : chunk_steps;
     HIP_TRY(hipEventRecord(q->ev[0], q->stream));
     // Steps are enqueued in chunks; after each chunk the control block is copied to pinned
     // memory and an event recorded.  The host stays one chunk ahead: chunk i+1 is already
@@ -1655,7 +1663,9 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->tx_cls.release(); q->row_tx.release(); q->perm.release(); q->cls_count.release(); q->cls_count_saved.release();
     q->inner.release(); q->row_sum.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
     q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
-    q->cum.release(); q->draw.release();
+    q->cum.release(); q->tile_total.release(); q->x_start.release(); q->boot_out.release();
+    q->batch.cls_count.release(); q->batch.inner.release(); q->batch.row_sum.release(); q->batch.x0.release();
+    q->batch.x1.release(); q->batch.part_max.release(); q->batch.part_flags.release(); q->batch.ctl.release();
     for (auto &e : q->ev) pool_event_release(e, true);
     for (auto &e : q->chunk_ev) pool_event_release(e, false);
     pool_pinned_release(q->pinned);
@@ -1697,9 +1707,10 @@ extern "C" int skm_quant_set_counts(skm_quant *q, const double *class_counts)
     return SKM_OK;
 }
 
-extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0,
-                                   const double *l, double rel_tol, double x_floor, int64_t max_iters,
-                                   double *out, int64_t *counts_out, int64_t *iters_out)
+namespace {
+int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0,
+                   const double *l, double rel_tol, double x_floor, int64_t max_iters,
+                   double *out, int64_t *counts_out, int64_t *iters_out, bool tpm)
 {
     if (!q || !x0 || !l || !out || n_boot < 0) return fail(SKM_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(q->mu);
@@ -1709,7 +1720,7 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
     // integer cumulative counts of the observed table
     SKM_TRY(q->cls_count_saved.ensure(C));
     SKM_TRY(q->cum.ensure(C));
-    SKM_TRY(q->draw.ensure(C));
+    SKM_TRY(q->tile_total.ensure(4096));
     HIP_TRY(hipMemcpyAsync(q->cls_count_saved.p, q->cls_count.p, C * 8, hipMemcpyDeviceToDevice, q->stream));
     std::vector<double> cnt(C);
     HIP_TRY(hipMemcpyAsync(cnt.data(), q->cls_count.p, C * 8, hipMemcpyDeviceToHost, q->stream));
@@ -1717,8 +1728,15 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
     std::vector<unsigned long long> cum(C);
     unsigned long long run = 0;
     for (int64_t c = 0; c < C; ++c) { run += (unsigned long long)cnt[c]; cum[c] = run; }
+    if (run >= (1ULL << 32)) return fail(SKM_ERR_STATE, "more than 2^32 - 1 units to resample");
+    const int64_t T = q->n_tx;
+    // the replicates' results stay in HBM and come back in groups (one copy per group, not one per replicate)
+    const int64_t group = std::max<int64_t>(1, std::min<int64_t>(n_boot, (int64_t)(1LL << 28) / T));
+    SKM_TRY(q->x_start.ensure(T));
+    SKM_TRY(q->boot_out.ensure((size_t)(group * T)));
     HIP_TRY(hipMemcpyAsync(q->cum.p, cum.data(), C * 8, hipMemcpyHostToDevice, q->stream));
-    HIP_TRY(hipMemcpyAsync(q->eff_len.p, l, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(hipMemcpyAsync(q->eff_len.p, l, T * 8, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(hipMemcpyAsync(q->x_start.p, x0, T * 8, hipMemcpyHostToDevice, q->stream));
     const double saved_total = q->n_total;
     const int64_t n_draws = (int64_t)run;            // n = class_count.sum(), infer.py:109
     int rc = SKM_OK;
@@ -1727,11 +1745,11 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
         (void)hipStreamSynchronize(q->stream);
         q->n_total = saved_total;
     });
-    for (int64_t b = 0; b < n_boot && rc == SKM_OK; ++b) {
-        HIP_TRY(hipMemsetAsync(q->draw.p, 0, C * 8, q->stream));
-        launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)b + (uint64_t)q->rank * 0x100000000ULL,
-                           q->draw.p, q->stream);
-        launch_u64_to_double(q->draw.p, C, q->cls_count.p, q->stream);
+    // One replicate the careful way (host-checked chunks of the single-problem EM): draw, EM from
+    // x_start, result to `dst` (HBM).
+    auto replicate_checked = [&](int64_t b, int64_t *it_out, double *dst) -> int {
+        if (!launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)b, q->tile_total.p, q->cls_count.p, 1, q->stream))
+            return fail(SKM_ERR_STATE, "class table too large to resample (%lld classes)", (long long)C);
         HIP_TRY(hipGetLastError());
         if (counts_out) {
             // internal (locality) class order -> caller's order; the counts fit a double exactly
@@ -1742,15 +1760,126 @@ extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, 
             HIP_TRY(hipStreamSynchronize(q->stream));
             for (int64_t c = 0; c < C; ++c) counts_out[b * C + c] = (int64_t)as_double[c];
         }
-        HIP_TRY(hipMemcpyAsync(q->x0.p, x0, q->n_tx * 8, hipMemcpyHostToDevice, q->stream));
+        HIP_TRY(hipMemcpyAsync(q->x0.p, q->x_start.p, T * 8, hipMemcpyDeviceToDevice, q->stream));
         q->n_total = (double)n_draws;
-        int64_t it = 0;
-        rc = em_run(q, rel_tol, x_floor, max_iters, 0, &it);
-        if (rc != SKM_OK) break;
-        HIP_TRY(hipMemcpy(out + b * q->n_tx, (it & 1) ? q->x1.p : q->x0.p, q->n_tx * 8, hipMemcpyDeviceToHost));
-        if (iters_out) iters_out[b] = it;
+        SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, it_out, 8));
+        HIP_TRY(hipMemcpyAsync(dst, (*it_out & 1) ? q->x1.p : q->x0.p, T * 8, hipMemcpyDeviceToDevice, q->stream));
+        if (iters_out) iters_out[b] = *it_out;
+        return SKM_OK;
+    };
+    DBuf<double> sums;
+    auto drop_sums = on_exit([&]() { sums.release(); });
+    auto send_home = [&](int64_t first, int64_t count) -> int {     // boot_out[0 .. count) = replicates first ..
+        if (count <= 0) return SKM_OK;
+        if (tpm) {                                                   // infer.py:127-129 on every replicate, numpy's sums
+            const int64_t n_blocks = (T + 8191) / 8192;
+            SKM_TRY(sums.ensure(n_blocks + 2));
+            double *const total = sums.p + n_blocks;
+            for (int64_t k = 0; k < count; ++k) {
+                double *const x = q->boot_out.p + k * T;
+                launch_np_sum(x, T, 1000000.0, sums.p, total, q->stream);
+                launch_divide(x, T, total + 1, true, 0.001, q->stream);
+                launch_np_sum(x, T, 1000000.0, sums.p, total, q->stream);
+                launch_divide(x, T, total + 1, false, 0.0, q->stream);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(out + first * T, q->boot_out.p, (size_t)count * T * 8, hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+        return SKM_OK;
+    };
+    // The first replicate goes the careful way and tells how many EM steps a replicate of this
+    // table takes.  So does every replicate when the resampled counts are wanted, a step cap is
+    // set, or a communicator is attached (its collectives must stay matched).  Otherwise the rest
+    // run EM_BATCH at a time through the batched EM: all draws, a budget of steps whose kernels
+    // turn into no-ops once every replicate's stopping rule has latched on the device, results
+    // picked on the device -- one host round trip per eight replicates.  A replicate that has not
+    // latched within the budget is done again the careful way: its draw is a function of
+    // (seed, b) alone, and the batched EM is the single-problem EM bit for bit.
+    int64_t first_steps = 0;
+    if (n_boot > 0) {
+        SKM_TRY(replicate_checked(0, &first_steps, q->boot_out.p));
+        SKM_TRY(send_home(0, 1));
+    }
+    const bool batched = !counts_out && !q->comm && max_iters <= 0;
+    if (!batched) {
+        for (int64_t b = 1; b < n_boot; ++b) {
+            int64_t it = 0;
+            SKM_TRY(replicate_checked(b, &it, q->boot_out.p));
+            SKM_TRY(send_home(b, 1));
+        }
+        return rc;
+    }
+    const int64_t slots = std::max<int64_t>(EM_BATCH, group / EM_BATCH * EM_BATCH);
+    SKM_TRY(q->boot_out.ensure((size_t)(slots * T)));
+    skm_quant::Batch &w = q->batch;
+    SKM_TRY(w.cls_count.ensure((size_t)C * EM_BATCH)); SKM_TRY(w.inner.ensure((size_t)C * EM_BATCH));
+    SKM_TRY(w.row_sum.ensure((size_t)std::max<int64_t>(q->n_rows, 1) * EM_BATCH));
+    SKM_TRY(w.x0.ensure((size_t)T * EM_BATCH)); SKM_TRY(w.x1.ensure((size_t)T * EM_BATCH));
+    SKM_TRY(w.part_max.ensure((size_t)EM_FINAL_BLOCKS * EM_BATCH));
+    SKM_TRY(w.part_flags.ensure((size_t)EM_FINAL_BLOCKS * EM_BATCH));
+    SKM_TRY(w.ctl.ensure(32));
+    EmBatchProblem p{};
+    p.n_tx = T; p.n_classes = C; p.n_rows = q->n_rows;
+    p.cls_offset = q->cls_offset.p; p.ids = q->ids.p; p.row_start = q->row_start.p; p.row_tx = q->row_tx.p;
+    p.tx_cls = q->tx_cls.p; p.tx_row = q->tx_row.p; p.eff_len = q->eff_len.p;
+    p.cls_count = w.cls_count.p; p.inner = w.inner.p; p.row_sum = w.row_sum.p;
+    p.x[0] = w.x0.p; p.x[1] = w.x1.p;
+    p.n_total = (double)n_draws; p.rel_tol = rel_tol; p.x_floor = x_floor;
+    p.ctl = w.ctl.p; p.part_max = w.part_max.p; p.part_flags = w.part_flags.p;
+    const int64_t budget = first_steps + std::max<int64_t>(8, first_steps / 2);
+    unsigned long long *const verdict = q->pinned + 64;          // 32 words of the pinned block
+    int64_t filled = 0, first_held = 1;                          // boot_out holds replicates first_held ..
+    for (int64_t g0 = 1; g0 < n_boot; g0 += EM_BATCH) {
+        const int n_here = (int)std::min<int64_t>(EM_BATCH, n_boot - g0);
+        for (int r = 0; r < EM_BATCH; ++r)       // (a short last group draws its spare replicates too: unused)
+            if (!launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)(g0 + r), q->tile_total.p,
+                                    w.cls_count.p + r, EM_BATCH, q->stream))
+                return fail(SKM_ERR_STATE, "class table too large to resample (%lld classes)", (long long)C);
+        launch_em_batch_start(q->x_start.p, T, w.x0.p, q->stream);
+        HIP_TRY(hipMemsetAsync(w.ctl.p, 0, 32 * 8, q->stream));
+        for (int64_t k = 0; k < budget; ++k) launch_em_batch_step(p, k, q->stream);
+        launch_em_batch_decide(p, budget, q->stream);
+        q->launches += 3 * budget + 1;
+        launch_em_batch_result(w.ctl.p, w.x0.p, w.x1.p, T, n_here, q->boot_out.p + filled * T, q->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(verdict, w.ctl.p, 32 * 8, hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+        for (int r = 0; r < n_here; ++r) {
+            if (verdict[24 + r])
+                return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
+            if (!verdict[8 + r]) {               // over budget: once more, with host-checked chunks
+                int64_t it = 0;
+                SKM_TRY(replicate_checked(g0 + r, &it, q->boot_out.p + (filled + r) * T));
+            } else {
+                if (iters_out) iters_out[g0 + r] = (int64_t)verdict[16 + r];
+                q->iters_total += (double)verdict[16 + r];
+            }
+        }
+        filled += n_here;
+        if (filled + EM_BATCH > slots || g0 + EM_BATCH >= n_boot) {
+            SKM_TRY(send_home(first_held, filled));
+            first_held += filled;
+            filled = 0;
+        }
     }
     return rc;
+}
+
+}  // namespace
+
+extern "C" int skm_quant_bootstrap(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0,
+                                   const double *l, double rel_tol, double x_floor, int64_t max_iters,
+                                   double *out, int64_t *counts_out, int64_t *iters_out)
+{
+    return bootstrap_impl(q, n_boot, seed, x0, l, rel_tol, x_floor, max_iters, out, counts_out, iters_out, false);
+}
+
+extern "C" int skm_quant_bootstrap_tpm(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0,
+                                       const double *l, double rel_tol, double x_floor, int64_t max_iters,
+                                       double *out, int64_t *iters_out)
+{
+    return bootstrap_impl(q, n_boot, seed, x0, l, rel_tol, x_floor, max_iters, out, nullptr, iters_out, true);
 }
 
 extern "C" int skm_quant_timing(skm_quant *q, double timing[4])

@@ -1,0 +1,280 @@
+// The EM of /root/reference/seekmer/infer.py:133-168 for EM_BATCH problems at once that share
+// their class structure and differ only in the class counts and the abundance vector: the
+// bootstrap replicates of `-b N` (infer.py:79-82, 108-111 -- every replicate resamples the
+// counts of the SAME class table and starts from the same estimate).
+//
+// A single problem's step is three launches of 5-13 us that move 8 useful bytes per 64-byte
+// sector they gather (x[t] per (class, transcript) pair, inner[c] per pair the other way round),
+// and a replicate takes ~30 of them: run one by one, a third of the time is gaps between
+// launches.  Here the replicates sit side by side -- x[t][r], inner[c][r], count[c][r], r = 0..7
+// -- so that one gathered sector carries all eight, the index arrays are read once for the
+// eight, and there is one launch where there were eight.
+//
+// Every replicate still runs ITS OWN iteration: the additions are the single-problem kernels'
+// additions in the same order (skm_em.hip), the stopping rule (infer.py:160) is judged per
+// replicate, and a replicate that has stopped is frozen (its x is carried from buffer to buffer
+// unchanged) while the others go on, so its result and its step count are exactly what the
+// one-by-one run gives -- bit for bit (tests/test_gpu_parity.py::test_bootstrap_draw_and_em).
+#include "skm_kernels.h"
+
+namespace skm {
+
+namespace {
+
+constexpr int R = EM_BATCH;
+static_assert(R == 8, "the row sums pair lanes and replicates eight by eight");
+enum { BCTL_ALL_DONE = 0, BCTL_LAST_STEP = 1, BCTL_DONE = 8, BCTL_ITERS = 16, BCTL_UNDEFINED = 24 };
+
+// The stopping rule for each replicate over the partials of finalize pass `steps_done`; returns
+// the mask of replicates that have stopped (now or earlier).  Every block of the next em_inner
+// launch evaluates it redundantly; the caller with `publish` (block 0) latches what is new.
+__device__ unsigned int evaluate_batch(const EmBatchProblem &p, int n_parts, int64_t steps_done, bool publish)
+{
+    __shared__ double s_max[32][R];
+    __shared__ unsigned int s_flags[32][R];
+    __shared__ unsigned int s_mask;
+    const int r = threadIdx.x & (R - 1), g = threadIdx.x >> 3;        // 256 lanes: 32 groups x 8 replicates
+    double m = 0.0;
+    unsigned int f = 0;
+    for (int b = g; b < n_parts; b += 32) {
+        const double o = p.part_max[b * R + r];
+        m = o > m ? o : m;
+        f |= p.part_flags[b * R + r];
+    }
+    s_max[g][r] = m;
+    s_flags[g][r] = f;
+    if (threadIdx.x == 0) s_mask = 0;
+    __syncthreads();
+    if (threadIdx.x < R) {
+        for (int k = 0; k < 32; ++k) {
+            m = s_max[k][r] > m ? s_max[k][r] : m;
+            f |= s_flags[k][r];
+        }
+        const bool latched = p.ctl[BCTL_DONE + r] != 0;
+        bool done, undefined = false;
+        if (!(f & 1u)) {
+            undefined = true;                 // numpy raises on max() of an empty selection
+            done = true;
+        } else {
+            done = (f & 2u) || !(m > p.rel_tol);                 // NaN propagates through max()
+        }
+        if (publish && !latched && done) {
+            if (undefined) p.ctl[BCTL_UNDEFINED + r] = 1;
+            p.ctl[BCTL_ITERS + r] = (unsigned long long)steps_done;
+            p.ctl[BCTL_DONE + r] = 1;
+        }
+        if (latched || done) atomicOr(&s_mask, 1u << r);
+    }
+    __syncthreads();
+    const unsigned int mask = s_mask;
+    if (publish && threadIdx.x == 0 && mask == (1u << R) - 1u && !p.ctl[BCTL_ALL_DONE]) {
+        p.ctl[BCTL_LAST_STEP] = (unsigned long long)steps_done;
+        p.ctl[BCTL_ALL_DONE] = 1;
+    }
+    return mask;
+}
+
+__global__ void __launch_bounds__(256)
+em_inner_batch_kernel(EmBatchProblem p, int parity, int eval_parts, int64_t steps_done)
+{
+    __shared__ int s_all;
+    if (threadIdx.x == 0) s_all = p.ctl[BCTL_ALL_DONE] != 0;       // one reading per block (see em_inner_kernel)
+    __syncthreads();
+    if (s_all) return;
+    if (eval_parts > 0 && evaluate_batch(p, eval_parts, steps_done, blockIdx.x == 0) == (1u << R) - 1u) return;
+    const double *__restrict__ x = p.x[parity];
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < p.n_classes;
+         c += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t begin = p.cls_offset[c], end = p.cls_offset[c + 1];
+        double s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = 0.0;
+        for (int64_t j = begin; j < end; ++j) {
+            const double *__restrict__ xt = x + (int64_t)p.ids[j] * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] += xt[r];
+        }
+        const double *__restrict__ count = p.cls_count + c * R;
+        double *__restrict__ inner = p.inner + c * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) inner[r] = s[r] / count[r];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+em_rows_batch_kernel(EmBatchProblem p, int parity)
+{
+    if (p.ctl[BCTL_ALL_DONE]) return;
+    const double *__restrict__ x = p.x[parity];
+    const int sub = threadIdx.x & 7;
+    for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; row < p.n_rows;
+         row += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int64_t begin = p.row_start[row], end = p.row_start[row + 1];
+        const double *__restrict__ xt = x + (int64_t)p.row_tx[row] * R;
+        double xr[R], s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { xr[r] = xt[r]; s[r] = 0.0; }
+        for (int64_t e = begin + sub; e < end; e += 8) {
+            const double *__restrict__ inner = p.inner + (int64_t)p.tx_cls[e] * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] += xr[r] / inner[r];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s[r] += __shfl_xor(s[r], 4, 8);
+            s[r] += __shfl_xor(s[r], 2, 8);
+            s[r] += __shfl_xor(s[r], 1, 8);
+        }
+        if (sub == 0) {
+            double *__restrict__ out = p.row_sum + row * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[r] = s[r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+em_finalize_batch_kernel(EmBatchProblem p, int parity)
+{
+    if (p.ctl[BCTL_ALL_DONE]) return;
+    __shared__ double s_max[4][R];
+    __shared__ unsigned int s_flags[4][R];
+    const double *__restrict__ x_old = p.x[parity];
+    double *__restrict__ x_new = p.x[parity ^ 1];
+    unsigned int stopped = 0;                 // replicates that are frozen
+#pragma unroll
+    for (int r = 0; r < R; ++r) stopped |= p.ctl[BCTL_DONE + r] ? 1u << r : 0u;
+    double local_max[R];
+    unsigned int flags[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { local_max[r] = 0.0; flags[r] = 0; }
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < p.n_tx;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        double a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = 0.0;
+        for (int64_t row = p.tx_row[t]; row < p.tx_row[t + 1]; ++row) {
+            const double *__restrict__ part = p.row_sum + row * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] += part[r];
+        }
+        const double l = p.eff_len[t];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double before = x_old[t * R + r];
+            double v = a[r] / l / p.n_total;                     // infer.py:158
+            if (v != v) v = 0.0;                                 // infer.py:159
+            if ((stopped >> r) & 1u) {
+                x_new[t * R + r] = before;                       // a stopped replicate keeps its result
+            } else {
+                x_new[t * R + r] = v;
+                if (v > p.x_floor) {                             // infer.py:160
+                    const double change = fabs(v - before) / v;
+                    if (change != change) flags[r] |= 2u;
+                    else if (change > local_max[r]) local_max[r] = change;
+                    flags[r] |= 1u;
+                }
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        for (int d = 32; d > 0; d >>= 1) {
+            const double o = __shfl_xor(local_max[r], d, 64);
+            local_max[r] = o > local_max[r] ? o : local_max[r];
+            flags[r] |= __shfl_xor(flags[r], d, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { s_max[wave][r] = local_max[r]; s_flags[wave][r] = flags[r]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < R) {
+        const int r = threadIdx.x;
+        double m = s_max[0][r];
+        unsigned int f = s_flags[0][r];
+        for (int w = 1; w < 4; ++w) { m = s_max[w][r] > m ? s_max[w][r] : m; f |= s_flags[w][r]; }
+        // a frozen replicate reports "selected, no change": it stays stopped whatever is judged
+        if ((stopped >> r) & 1u) { m = 0.0; f = 1u; }
+        p.part_max[blockIdx.x * R + r] = m;
+        p.part_flags[blockIdx.x * R + r] = f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+em_decide_batch_kernel(EmBatchProblem p, int n_parts, int64_t steps_done)
+{
+    __shared__ int s_all;
+    if (threadIdx.x == 0) s_all = p.ctl[BCTL_ALL_DONE] != 0;
+    __syncthreads();
+    if (s_all) return;
+    evaluate_batch(p, n_parts, steps_done, true);
+}
+
+// x[t][r] = start[t]
+__global__ void __launch_bounds__(256)
+em_batch_start_kernel(const double *__restrict__ start, int64_t n_tx, double *__restrict__ x)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx * R;
+         i += (int64_t)gridDim.x * blockDim.x) x[i] = start[i / R];
+}
+
+// out[r][t] = the result of replicate r (r < n_out): every replicate's last x has been carried to
+// the buffer the last executed step wrote
+__global__ void __launch_bounds__(256)
+em_batch_result_kernel(const unsigned long long *__restrict__ ctl, const double *__restrict__ x0,
+                       const double *__restrict__ x1, int64_t n_tx, int n_out, double *__restrict__ out)
+{
+    const double *__restrict__ x = (ctl[BCTL_LAST_STEP] & 1ULL) ? x1 : x0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx * n_out;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_tx, t = i - r * n_tx;
+        out[i] = x[t * R + r];
+    }
+}
+
+inline unsigned grid_of(int64_t items, int per_block, int64_t cap = 256 * 8)
+{
+    int64_t blocks = (items + per_block - 1) / per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+int em_batch_final_blocks(const EmBatchProblem &p)
+{
+    int64_t blocks = (p.n_tx + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
+    return (int)blocks;
+}
+
+void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream)
+{
+    const int parity = (int)(step & 1);
+    hipLaunchKernelGGL(em_inner_batch_kernel, dim3(grid_of(p.n_classes, 256)), dim3(256), 0, stream, p, parity,
+                       step > 0 ? em_batch_final_blocks(p) : 0, step);
+    hipLaunchKernelGGL(em_rows_batch_kernel, dim3(grid_of(p.n_rows, 32)), dim3(256), 0, stream, p, parity);
+    hipLaunchKernelGGL(em_finalize_batch_kernel, dim3((unsigned)em_batch_final_blocks(p)), dim3(256), 0, stream, p,
+                       parity);
+}
+
+void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_decide_batch_kernel, dim3(1), dim3(256), 0, stream, p, em_batch_final_blocks(p), steps_done);
+}
+
+void launch_em_batch_start(const double *start, int64_t n_tx, double *x, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_batch_start_kernel, dim3(grid_of(n_tx * R, 256)), dim3(256), 0, stream, start, n_tx, x);
+}
+
+void launch_em_batch_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n_tx,
+                            int n_out, double *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_batch_result_kernel, dim3(grid_of(n_tx * n_out, 256)), dim3(256), 0, stream, ctl, x0, x1,
+                       n_tx, n_out, out);
+}
+
+}  // namespace skm

@@ -155,6 +155,41 @@ void launch_em_decide(const EmProblem &p, int64_t steps_done, hipStream_t stream
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream);
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream);
 void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream);
+// out = the result of an EM that latched after ctl[1] steps (x0 if even, x1 if odd)
+void launch_em_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n, double *out,
+                      hipStream_t stream);
+
+// ---- the EM for EM_BATCH problems of one class structure side by side (skm_em_batch.hip):
+// the bootstrap replicates.  Arrays with a replicate dimension are [item][EM_BATCH].
+constexpr int EM_BATCH = 8;
+struct EmBatchProblem {
+    int64_t n_tx, n_classes, n_rows;
+    const int64_t *cls_offset;    // shared structure: as EmProblem
+    const int32_t *ids;
+    const int64_t *row_start;
+    const int32_t *row_tx;
+    const int32_t *tx_cls;
+    const int64_t *tx_row;
+    const double *eff_len;
+    const double *cls_count;      // [C][EM_BATCH]
+    double *inner;                // [C][EM_BATCH]
+    double *row_sum;              // [R][EM_BATCH]
+    double *x[2];                 // [T][EM_BATCH] ping-pong
+    double n_total;               // the same for every replicate (a resample keeps the total)
+    double rel_tol, x_floor;
+    // control block (32 words): [0] all stopped [1] step at which the last one stopped,
+    // [8 + r] replicate r stopped, [16 + r] its step count, [24 + r] undefined (no x above x_floor)
+    unsigned long long *ctl;
+    double *part_max;             // [EM_FINAL_BLOCKS][EM_BATCH]
+    unsigned int *part_flags;     // [EM_FINAL_BLOCKS][EM_BATCH]
+};
+// one step (inner, rows, finalize); step > 0 first judges the step before it
+void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream);
+void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream);
+void launch_em_batch_start(const double *start, int64_t n_tx, double *x, hipStream_t stream);
+// out[r][t], r < n_out: the replicates' results once everything queued has run
+void launch_em_batch_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n_tx,
+                            int n_out, double *out, hipStream_t stream);
 
 // device-side construction of the two CSR views (hipCUB sorts/scans + small kernels)
 struct QuantBuild {
@@ -185,9 +220,12 @@ void launch_reciprocal(const double *l, int64_t n, double *x, hipStream_t stream
 void launch_divide(double *x, int64_t n, const double *s, bool threshold, double floor, hipStream_t stream);
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
                               double *out, hipStream_t stream);
-void launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_t n_draws,
-                        uint64_t seed, uint64_t stream_id, unsigned long long *counts,
-                        hipStream_t stream);
+// multinomial(n_draws, counts / n_draws) over the classes whose inclusive cumulative counts are
+// `cum`: counts[c * stride] = draws of class c (f8).  tile_total: 4096 unsigned ints of scratch.
+// false = table too large for the tiled draw.
+bool launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_t n_draws,
+                        uint64_t seed, uint64_t stream_id, unsigned int *tile_total, double *counts,
+                        int stride, hipStream_t stream);
 void launch_u64_to_double(const unsigned long long *in, int64_t n, double *out, hipStream_t stream);
 void launch_double_to_u64(const double *in, int64_t n, unsigned long long *out, hipStream_t stream);
 

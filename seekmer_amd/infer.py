@@ -137,10 +137,19 @@ class _QuantHandle:
         _native.check(_native.hip().skm_quant_set_counts(self.handle,
                                                          _native.ptr(counts, _native.c_f64p)))
 
-    def bootstrap(self, n_boot, seed, x0, l, want_counts=False):
+    def bootstrap(self, n_boot, seed, x0, l, want_counts=False, tpm=False):
+        """(results [n_boot, n_tx], resampled counts or None, EM steps per replicate); tpm: the
+        results already scaled as quantify() scales them (seekmer/infer.py:127-129)."""
         x0 = numpy.ascontiguousarray(x0, dtype='f8')
         l = numpy.ascontiguousarray(l, dtype='f8')
         out = numpy.zeros((n_boot, self.n_tx), dtype='f8')
+        if tpm and not want_counts:
+            iters = numpy.zeros(max(n_boot, 1), dtype=numpy.int64)
+            _native.check(_native.hip().skm_quant_bootstrap_tpm(
+                self.handle, n_boot, seed, _native.ptr(x0, _native.c_f64p),
+                _native.ptr(l, _native.c_f64p), REL_TOL, X_FLOOR, 0,
+                _native.ptr(out, _native.c_f64p), _native.ptr(iters, _native.c_i64p)))
+            return out, None, iters[:n_boot]
         counts = numpy.zeros((n_boot, max(self.n_classes, 1)), dtype=numpy.int64) if want_counts else None
         iters = numpy.zeros(max(n_boot, 1), dtype=numpy.int64)
         _native.check(_native.hip().skm_quant_bootstrap(
@@ -262,11 +271,11 @@ def bootstrap_quantify(results, x0, n_boot, seed=None):
     x /= x.sum()
     quant, owned = _quant_for(results)
     try:
-        out, _, _ = quant.bootstrap(n_boot, seed, x, transcript_length)
+        out, _, _ = quant.bootstrap(n_boot, seed, x, transcript_length, tpm=True)
     finally:
         if owned:
             quant.close()
-    return [_tpm(out[b].copy()) for b in range(n_boot)]
+    return list(out)
 
 
 def em(x, l, class_map, class_count, fixed_iters=0, return_iters=False, device=0):

@@ -485,9 +485,17 @@ def test_bootstrap_draw_and_em(oracle, native_libs):
     n_boot = 100
     out, counts, iters = quant.bootstrap(n_boot, 1234, x0, l, want_counts=True)
     out2, counts2, _ = quant.bootstrap(n_boot, 1234, x0, l, want_counts=True)
+    # without the counts the replicates run eight at a time through the batched EM
+    # (skm_em_batch.hip): the same draws, the same additions -- the same bits and step counts
+    out8, _, iters8 = quant.bootstrap(n_boot, 1234, x0, l)
+    out5, _, iters5 = quant.bootstrap(5, 1234, x0, l)             # (a short last group)
     quant.close()
     np.testing.assert_array_equal(counts, counts2)      # seeded: reproducible
     np.testing.assert_array_equal(out, out2)
+    np.testing.assert_array_equal(out8, out)
+    np.testing.assert_array_equal(iters8, iters)
+    np.testing.assert_array_equal(out5, out[:5])
+    np.testing.assert_array_equal(iters5, iters[:5])
     n = class_count.sum()
     assert (counts.sum(axis=1) == n).all()
     p = class_count / n
@@ -526,6 +534,9 @@ def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs):
     quant = infer._QuantHandle.from_map_result(result, n_tx)
     n_boot = 100
     out, counts, iters = quant.bootstrap(n_boot, 20240, x0, eff, want_counts=True)
+    out8, _, iters8 = quant.bootstrap(n_boot, 20240, x0, eff)    # batched EM: bit for bit the same
+    np.testing.assert_array_equal(out8, out)
+    np.testing.assert_array_equal(iters8, iters)
     # the handle holds the observed counts again afterwards
     x_main, it_main = quant.em(1.0 / eff / (1.0 / eff).sum(), eff)
     quant.close()
@@ -546,7 +557,7 @@ def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs):
     # and through the module surface: bootstrap_quantify returns TPM vectors (sum 1e6)
     tpms = infer.bootstrap_quantify(summarized, main, 3, seed=20240)
     assert len(tpms) == 3 and all(abs(t.sum() - 1e6) < 1e-3 for t in tpms)
-    np.testing.assert_allclose(tpms[0], infer._tpm(out[0].copy()), rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(tpms[0], infer._tpm(out[0].copy()))   # numpy's sums restated on the device
 
 
 def test_cli_end_to_end(oracle, native_libs, chr21, chr21_oracle_index, pairs21, tmp_path):
