@@ -1,8 +1,9 @@
 """Build oracle/_ref/: the reference's header-inline primitives, compiled from
 /root/reference where the sources lie (nothing copied), through the harness
 oracle/ref_primitives.pyx.  Only runs where /root/reference exists (this
-container); the GPU box receives the prebuilt .so.  Outputs go to oracle/_ref/
-only (git-ignored, not gpurun-ignored)."""
+container).  Outputs go to oracle/_ref/ only, which is git-ignored AND gpurun-ignored: nothing
+compiled from the reference travels to the GPU box -- the pin that travels is the fixture this
+build wrote, tests/golden/primitives.json."""
 import os
 import subprocess
 import sys

@@ -26,8 +26,8 @@ static_assert(R == 8, "the row sums pair lanes and replicates eight by eight");
 enum { BCTL_ALL_DONE = 0, BCTL_LAST_STEP = 1, BCTL_DONE = 8, BCTL_ITERS = 16, BCTL_UNDEFINED = 24 };
 
 // The stopping rule for each replicate over the partials of finalize pass `steps_done`; returns
-// the mask of replicates that have stopped (now or earlier).  Every block of the next em_inner
-// launch evaluates it redundantly; the caller with `publish` (block 0) latches what is new.
+// the mask of replicates that have stopped (now or earlier).  Block 0 of the next em_inner launch
+// evaluates it; with `publish` it latches what is new.
 __device__ unsigned int evaluate_batch(const EmBatchProblem &p, int n_parts, int64_t steps_done, bool publish)
 {
     __shared__ double s_max[32][R];
@@ -78,10 +78,13 @@ __global__ void __launch_bounds__(256)
 em_inner_batch_kernel(EmBatchProblem p, int parity, int eval_parts, int64_t steps_done)
 {
     __shared__ int s_all;
-    if (threadIdx.x == 0) s_all = p.ctl[BCTL_ALL_DONE] != 0;       // one reading per block (see em_inner_kernel)
+    if (threadIdx.x == 0) s_all = p.ctl[BCTL_ALL_DONE] != 0;       // one reading per block
     __syncthreads();
     if (s_all) return;
-    if (eval_parts > 0 && evaluate_batch(p, eval_parts, steps_done, blockIdx.x == 0) == (1u << R) - 1u) return;
+    // block 0 judges the step before this one and latches what has stopped; the other blocks do not
+    // wait (see em_inner_kernel: a pass of `inner` nobody reads, once per batch)
+    if (eval_parts > 0 && blockIdx.x == 0
+            && evaluate_batch(p, eval_parts, steps_done, true) == (1u << R) - 1u) return;
     const double *__restrict__ x = p.x[parity];
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < p.n_classes;
          c += (int64_t)gridDim.x * blockDim.x) {
