@@ -249,6 +249,7 @@ struct skm_fastq {
     int shard_rank = 0, shard_world = 1;      // this reader hands out batches k with k % world == rank
     int64_t seq_batch = 0;                    // sequential engine: index of the next batch it parses
     int64_t last_index = -1;                  // index (in the whole sample) of the batch handed out last
+    int64_t last_read_len = -1;               // its reads' common length, or -1
     // ---- sequential engine
     size_t next_path = 0;
     LineReader r1, r2;
@@ -539,6 +540,7 @@ static int next_parallel(skm_fastq *q, int64_t *n_units)
     q->cur = q->ready[q->next_deliver];
     q->ready.erase(q->next_deliver);
     q->last_index = q->shard_rank + q->next_deliver * q->shard_world;
+    q->last_read_len = q->cur->read_len;
     q->next_deliver++;
     const bool failed = q->failed;
     hold.unlock();
@@ -615,6 +617,7 @@ extern "C" int skm_fastq_next(skm_fastq *q, int64_t *n_units, const char **bases
     const int64_t index = q->seq_batch++;
     if (*n_units != 0 && index % q->shard_world != q->shard_rank) continue;
     q->last_index = index;
+    q->last_read_len = b->read_len;
     if (bases) *bases = b->bases.p;
     if (offsets) *offsets = b->offsets.p;
     if (names) *names = b->names.p;
@@ -635,7 +638,7 @@ extern "C" int skm_fastq_set_shard(skm_fastq *q, int rank, int world)
 extern "C" int skm_fastq_batch_read_length(const skm_fastq *q, int64_t *read_len)
 {
     if (!q || !read_len) return SKM_ERR_ARG;
-    *read_len = q->cur && q->cur->read_len >= 0 ? q->cur->read_len : -1;
+    *read_len = q->last_read_len >= 0 ? q->last_read_len : -1;   // (survives skm_fastq_detach)
     return SKM_OK;
 }
 

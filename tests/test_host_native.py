@@ -434,6 +434,8 @@ def test_parallel_fastq_engine_equals_sequential(native_libs, tmp_path, paired):
     parallel = [(b.count, b.names, b.reads, b.first_unit) for b in feeder]
     assert feeder.parallel is True
     assert parallel == sequential
+    assert all(b.uniform_len is None for b in common.NativeReadFeeder(paths, paired=paired, batch_units=700,
+                                                                      threads=3))     # ragged reads
     assert [p[0] for p in parallel] == [700] * 6 + [sum(counts) - 4200]
     assert [p[3] for p in parallel] == [700 * k for k in range(7)]
     # leaving the loop early with workers in flight must not hang or leak
@@ -466,6 +468,9 @@ def test_sharded_feeders_partition_the_sample(native_libs, tmp_path, threads):
     whole = [(b.first_unit, b.count, b.reads) for b in
              common.NativeReadFeeder([path], paired=False, batch_units=300, threads=threads)]
     assert [w[0] for w in whole] == [300 * k for k in range(8)]
+    # every read is 36 bases long: the batches say so (they can be handed over without offsets)
+    assert [b.uniform_len for b in common.NativeReadFeeder([path], paired=False, batch_units=300,
+                                                           threads=threads)] == [36] * 8
     for world in (2, 3, 9):
         parts = []
         for rank in range(world):
