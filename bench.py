@@ -208,8 +208,10 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
             'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
             'parse_only': n_units / t_parse, 'text_GBps': need / best[0] / 1e9, 'parse_threads': threads,
             'parallel_engine': bool(best[2]),
-            'how': 'two FASTQ files (%d bytes per record, RAM disk) -> NativeReadFeeder(threads=%d, pinned) in '
-                   '%d batches -> skm_mapper_map_batch_async -> skm_quant_infer; best of %d passes'
+            'how': 'two FASTQ files (%d bytes per record, RAM disk; the reader keeps a file mapped between '
+                   'passes and its page-locked slabs pooled, each pass counts the newlines and parses anew) -> '
+                   'NativeReadFeeder(threads=%d, pinned) in %d batches -> skm_mapper_map_batch[_uniform]_async -> '
+                   'skm_quant_infer; best of %d passes'
                    % (2 * read_len + 19, threads, pieces, passes)}
     finally:
         shutil.rmtree(folder, ignore_errors=True)

@@ -178,6 +178,33 @@ constexpr size_t MAX_SPARE = 32;
 
 constexpr size_t BLOCK = 1 << 20;          // granularity of the newline index
 
+// Mappings outlive their reader.  Setting up and tearing down the page tables of a multi-gigabyte
+// text file costs more than parsing it (4.4 GB: ~50 ms of faults, ~100 ms of munmap with the
+// process's memory-map lock held -- the quantification that follows a mapping run stalled on
+// exactly that), so a mapping is kept, keyed by the file's identity, for the next reader of the
+// same file; mappings nobody uses are dropped oldest first beyond MAP_KEEP_BYTES, in the
+// background and in pieces.
+struct MapEntry {
+    std::string path;
+    dev_t dev; ino_t ino; off_t size; long mtime_s, mtime_ns;
+    const char *p;
+    int users;
+    uint64_t stamp;
+};
+std::mutex g_map_lock;
+std::vector<MapEntry> g_maps;
+uint64_t g_map_stamp = 0;
+constexpr size_t MAP_KEEP_BYTES = 64ull << 30;
+
+void unmap_in_pieces(const char *p, size_t n)
+{
+    constexpr size_t PIECE = 32u << 20;            // the memory-map lock is released between pieces
+    for (size_t at = 0; at < n; at += PIECE) {
+        munmap((void *)(p + at), std::min(PIECE, n - at));
+        std::this_thread::yield();
+    }
+}
+
 struct Mapped {
     const char *p = nullptr;
     size_t n = 0;
@@ -192,15 +219,53 @@ struct Mapped {
         if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
         n = (size_t)st.st_size;
         if (n) {
+            std::lock_guard<std::mutex> hold(g_map_lock);
+            for (auto &e : g_maps)
+                if (e.dev == st.st_dev && e.ino == st.st_ino && e.size == st.st_size
+                        && e.mtime_s == (long)st.st_mtim.tv_sec && e.mtime_ns == (long)st.st_mtim.tv_nsec) {
+                    e.users++;
+                    e.stamp = ++g_map_stamp;
+                    p = e.p;
+                    close(fd);
+                    return true;
+                }
             void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); return false; }
             (void)madvise(m, n, MADV_WILLNEED);
             p = (const char *)m;
+            g_maps.push_back(MapEntry{path, st.st_dev, st.st_ino, st.st_size, (long)st.st_mtim.tv_sec,
+                                      (long)st.st_mtim.tv_nsec, p, 1, ++g_map_stamp});
         }
         close(fd);
         return true;
     }
-    void unmap() { if (p) munmap((void *)p, n); p = nullptr; n = 0; }
+    // give the mapping back: it stays cached; what exceeds the budget goes in the background
+    void unmap()
+    {
+        if (!p) return;
+        std::vector<std::pair<const char *, size_t>> drop;
+        {
+            std::lock_guard<std::mutex> hold(g_map_lock);
+            size_t kept = 0;
+            for (auto &e : g_maps) {
+                if (e.p == p && e.users > 0) e.users--;
+                kept += (size_t)e.size;
+            }
+            while (kept > MAP_KEEP_BYTES) {
+                int oldest = -1;
+                for (size_t i = 0; i < g_maps.size(); ++i)
+                    if (g_maps[i].users == 0 && (oldest < 0 || g_maps[i].stamp < g_maps[(size_t)oldest].stamp)) oldest = (int)i;
+                if (oldest < 0) break;
+                drop.emplace_back(g_maps[(size_t)oldest].p, (size_t)g_maps[(size_t)oldest].size);
+                kept -= (size_t)g_maps[(size_t)oldest].size;
+                g_maps.erase(g_maps.begin() + oldest);
+            }
+        }
+        if (!drop.empty())
+            std::thread([drop]() { for (auto &d : drop) unmap_in_pieces(d.first, d.second); }).detach();
+        p = nullptr;
+        n = 0;
+    }
 
     // byte offset where line `line` starts (line <= lines; line == lines -> end of file)
     size_t line_start(int64_t line) const
@@ -307,25 +372,7 @@ struct skm_fastq {
     {
         stop_workers();
         for (auto &kv : ready) delete kv.second;
-        if (!files.empty()) {
-            // Tearing down gigabytes of 4 KiB mappings takes ~25 ms per GB with the process's
-            // memory-map lock held: not on the caller's time, and in 32 MiB pieces so that the
-            // caller's own page faults and allocations (the quantification that follows) slip in
-            // between instead of waiting out the whole teardown.
-            std::vector<Mapped> gone;
-            gone.swap(files);
-            std::thread([gone]() mutable {
-                constexpr size_t PIECE = 32u << 20;
-                for (auto &f : gone) {
-                    if (!f.p) continue;
-                    for (size_t at = 0; at < f.n; at += PIECE) {
-                        munmap((void *)(f.p + at), std::min(PIECE, f.n - at));
-                        std::this_thread::yield();
-                    }
-                    f.p = nullptr;
-                }
-            }).detach();
-        }
+        for (auto &f : files) f.unmap();               // (back to the process-wide cache of mappings)
         if (cur) skm_fastq_recycle(nullptr, cur);      // (grown, touched, maybe page-locked: worth keeping)
         cur = nullptr;
     }
