@@ -18,15 +18,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seekmer_amd import common, index_builder, infer, mapper, synth   # noqa: E402
 
 
-def write_fastq(path, reads2d, mate):
-    quality = b'I' * reads2d.shape[1]
-    with open(path, 'wb') as f:
-        for first in range(0, reads2d.shape[0], 100000):
-            chunk = reads2d[first:first + 100000]
-            f.write(b''.join(b'@r%d/%d\n%s\n+\n%s\n' % (first + i, mate, chunk[i].tobytes(), quality)
-                             for i in range(chunk.shape[0])))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--genes', type=int, default=20000)
@@ -64,16 +55,14 @@ def main():
     del result, rm, batch
 
     # ---- FASTQ text
-    reads2d = bases[:2 * args.pairs * args.read_len].reshape(args.pairs, 2, args.read_len)
     r1, r2 = work / 'r1.fastq', work / 'r2.fastq'
-    write_fastq(r1, reads2d[:, 0], 1)
-    write_fastq(r2, reads2d[:, 1], 2)
+    synth.write_fastq(bases, args.pairs, args.read_len, True, r1, r2)
     size = (r1.stat().st_size + r2.stat().st_size) / 1e9
     for rep in range(2):
         t0 = time.perf_counter()
         n = sum(b.count for b in common.NativeReadFeeder([r1, r2], True))
         dt = time.perf_counter() - t0
-        print('native reader alone rep %d: %d pairs in %.2f s = %.2f M pairs/s (%.2f GB/s of FASTQ text)'
+        print('native reader alone (sequential engine) rep %d: %d pairs in %.2f s = %.2f M pairs/s (%.2f GB/s of FASTQ text)'
               % (rep, n, dt, n / dt / 1e6, size / dt), flush=True)
     for rep in range(2):
         t0 = time.perf_counter()
@@ -94,7 +83,7 @@ def main():
 
     index2 = common.KMerIndex.load(index_path); lap('index load')
     index2.device_handle(0); lap('index upload')
-    feeder = common.NativeReadFeeder([r1, r2], paired=True)
+    feeder = infer._feeder([r1, r2], True, None, None, False)
     map_result = mapper.map_reads(index2, feeder, job_count=args.jobs); lap('map_reads')
     summarized = map_result.summarize(); lap('summarize')
     tpm = infer.quantify(summarized); lap('quantify')

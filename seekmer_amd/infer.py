@@ -26,7 +26,7 @@ X_FLOOR = 1e-8          # seekmer/infer.py:160
 
 
 def run(index_path, output_path, fastq_paths, job_count, save_readmap,
-        single_ended, bootstrap, debug, device=0, seed=None, parse_threads=0, **__):
+        single_ended, bootstrap, debug, device=0, seed=None, parse_threads=None, **__):
     """The entrypoint of the inference module (seekmer/infer.py:27-85).
 
     Started as one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m
@@ -51,8 +51,7 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
     _LOG.info('Inferring transcript abundance')
     index = common.KMerIndex.load(index_path)
     _LOG.info('Mapping all reads')
-    read_feeder = common.NativeReadFeeder(fastq_paths, paired=not single_ended, threads=parse_threads,
-                                          pinned=parse_threads > 0, shard=ranks.shard)
+    read_feeder = _feeder(fastq_paths, not single_ended, parse_threads, ranks.shard, save_readmap)
     map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
                                   readmap=readmap, debug=debug, device=device)
     _LOG.info('Mapped all reads')
@@ -73,6 +72,27 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
                        main_result, bootstrapped_results)
         _LOG.info('Wrote results to %s', output_path)
     ranks.close()
+
+
+def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches):
+    """The native reader as run() uses it.  parse_threads None = choose: plain files are parsed by up
+    to 8 threads in batches of 2^20 units (the batching only paces the hand-over: results do not
+    depend on it), into page-locked slabs when there is enough text (> 4 GiB) to pay for pinning
+    them; 0 = the sequential engine in the reference's batches of 65 536 (seekmer/common.py:17),
+    which `-m` keeps so that readmap.txt is written batch by batch as the reference writes it."""
+    import os
+    if parse_threads is None:
+        parse_threads = 0 if keep_reference_batches else min(8, os.cpu_count() or 1)
+    if parse_threads <= 0:
+        return common.NativeReadFeeder(fastq_paths, paired=paired, shard=shard)
+    total = 0
+    for path in fastq_paths:
+        try:
+            total += os.path.getsize(str(path))
+        except OSError:
+            pass
+    return common.NativeReadFeeder(fastq_paths, paired=paired, batch_units=1 << 20, threads=parse_threads,
+                                   pinned=total > (4 << 30), shard=shard)
 
 
 def finish(map_result, ranks, quantify_ranks):
@@ -389,5 +409,6 @@ def add_subcommand_parser(subparsers):
     parser.add_argument('--device', type=int, default=0, help='GPU ordinal (default 0)')
     parser.add_argument('--seed', type=int, default=None,
                         help='seed of the bootstrap resampling (default: random)')
-    parser.add_argument('--parse-threads', type=int, dest='parse_threads', default=0, metavar='N',
-                        help='parse plain FASTQ files with N threads into page-locked memory (default: 1 thread)')
+    parser.add_argument('--parse-threads', type=int, dest='parse_threads', default=None, metavar='N',
+                        help='parse plain FASTQ files with N threads (default: up to 8; 0: one thread, '
+                             'the batches of the reference)')
