@@ -302,7 +302,7 @@ def main():
         comm_id = bytes(buf.numpy().tobytes())
     comm = ctypes.c_void_p()
     if comm_id is not None:                # one communicator per process, reused by every step
-        _native.check(hip.skm_comm_create(device, comm_id, rank, world, ctypes.byref(comm)))
+        comm = parallel.create_comm(device, comm_id, rank, world)     # (RCCL's banner goes to stderr)
     rccl_ranks = 0
     if comm:
         n = ctypes.c_int(0)

@@ -146,16 +146,42 @@ class Ranks:
         self.dist = None
 
 
-def make_comm(ranks, device):
-    """One RCCL communicator per process (skm_comm*), or None for a single rank."""
+class stdout_to_stderr:
+    """RCCL announces itself ("RCCL version : ...") on the C-level standard output when a
+    communicator is made; a program whose standard output is its result (bench.py's one JSON line,
+    a pipeline reading abundance tables) wants that on stderr.  File descriptor 1 is pointed at
+    descriptor 2 for the duration and restored."""
+
+    def __enter__(self):
+        import os
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
+def create_comm(device, comm_id, rank, world):
+    """skm_comm_create with RCCL's banner kept off the standard output."""
     import ctypes
     from . import _native
+    comm = ctypes.c_void_p()
+    with stdout_to_stderr():
+        _native.check(_native.hip().skm_comm_create(device, comm_id, rank, world, ctypes.byref(comm)))
+    return comm
+
+
+def make_comm(ranks, device):
+    """One RCCL communicator per process (skm_comm*), or None for a single rank."""
     if ranks.world <= 1:
         return None
-    comm_id = broadcast_comm_id(ranks.dist, ranks.rank)
-    comm = ctypes.c_void_p()
-    _native.check(_native.hip().skm_comm_create(device, comm_id, ranks.rank, ranks.world, ctypes.byref(comm)))
-    return comm
+    return create_comm(device, broadcast_comm_id(ranks.dist, ranks.rank), ranks.rank, ranks.world)
 
 
 def destroy_comm(comm):
