@@ -221,13 +221,34 @@ em_batch_start_kernel(const double *__restrict__ start, int64_t n_tx, double *__
          i += (int64_t)gridDim.x * blockDim.x) x[i] = start[i / R];
 }
 
+// replicate `from` of one working set -> replicate `to` of another: its abundances (the buffer the
+// next step reads) and its counts
+__global__ void __launch_bounds__(256)
+em_batch_move_kernel(const double *__restrict__ x_from, const double *__restrict__ count_from, int from,
+                     double *__restrict__ x_to, double *__restrict__ count_to, int to, int64_t n_tx,
+                     int64_t n_classes)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx + n_classes;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_tx) x_to[i * R + to] = x_from[i * R + from];
+        else count_to[(i - n_tx) * R + to] = count_from[(i - n_tx) * R + from];
+    }
+}
+
+// control block of a working set whose replicates `n_live` .. R-1 are unused: they count as stopped
+__global__ void em_batch_ctl_kernel(unsigned long long *ctl, int n_live)
+{
+    const int i = threadIdx.x;
+    if (i < 32) ctl[i] = (i >= BCTL_DONE + n_live && i < BCTL_DONE + R) ? 1ULL : 0ULL;
+}
+
 // out[r][t] = the result of replicate r (r < n_out): every replicate's last x has been carried to
-// the buffer the last executed step wrote
+// the buffer the last executed step wrote (ctl == nullptr: the caller knows it, and passes it as x0)
 __global__ void __launch_bounds__(256)
 em_batch_result_kernel(const unsigned long long *__restrict__ ctl, const double *__restrict__ x0,
                        const double *__restrict__ x1, int64_t n_tx, int n_out, double *__restrict__ out)
 {
-    const double *__restrict__ x = (ctl[BCTL_LAST_STEP] & 1ULL) ? x1 : x0;
+    const double *__restrict__ x = (ctl && (ctl[BCTL_LAST_STEP] & 1ULL)) ? x1 : x0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx * n_out;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / n_tx, t = i - r * n_tx;
@@ -253,11 +274,11 @@ int em_batch_final_blocks(const EmBatchProblem &p)
     return (int)blocks;
 }
 
-void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream)
+void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream, bool judge_previous)
 {
     const int parity = (int)(step & 1);
     hipLaunchKernelGGL(em_inner_batch_kernel, dim3(grid_of(p.n_classes, 256)), dim3(256), 0, stream, p, parity,
-                       step > 0 ? em_batch_final_blocks(p) : 0, step);
+                       step > 0 && judge_previous ? em_batch_final_blocks(p) : 0, step);
     hipLaunchKernelGGL(em_rows_batch_kernel, dim3(grid_of(p.n_rows, 32)), dim3(256), 0, stream, p, parity);
     hipLaunchKernelGGL(em_finalize_batch_kernel, dim3((unsigned)em_batch_final_blocks(p)), dim3(256), 0, stream, p,
                        parity);
@@ -271,6 +292,18 @@ void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStre
 void launch_em_batch_start(const double *start, int64_t n_tx, double *x, hipStream_t stream)
 {
     hipLaunchKernelGGL(em_batch_start_kernel, dim3(grid_of(n_tx * R, 256)), dim3(256), 0, stream, start, n_tx, x);
+}
+
+void launch_em_batch_move(const double *x_from, const double *count_from, int from, double *x_to,
+                          double *count_to, int to, int64_t n_tx, int64_t n_classes, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_batch_move_kernel, dim3(grid_of(n_tx + n_classes, 256)), dim3(256), 0, stream, x_from,
+                       count_from, from, x_to, count_to, to, n_tx, n_classes);
+}
+
+void launch_em_batch_ctl(unsigned long long *ctl, int n_live, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_batch_ctl_kernel, dim3(1), dim3(64), 0, stream, ctl, n_live);
 }
 
 void launch_em_batch_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n_tx,

@@ -183,15 +183,22 @@ struct EmBatchProblem {
     double *part_max;             // [EM_FINAL_BLOCKS][EM_BATCH]
     unsigned int *part_flags;     // [EM_FINAL_BLOCKS][EM_BATCH]
 };
-// one step (inner, rows, finalize); step > 0 first judges the step before it
-void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream);
+// one step (inner, rows, finalize); step > 0 first judges the step before it -- unless the
+// partials of that step are not this working set's (replicates moved in from elsewhere)
+void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream, bool judge_previous = true);
 void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream);
 void launch_em_batch_start(const double *start, int64_t n_tx, double *x, hipStream_t stream);
+// replicate `from` of one working set (abundances read by the next step, counts) -> replicate
+// `to` of another
+void launch_em_batch_move(const double *x_from, const double *count_from, int from, double *x_to,
+                          double *count_to, int to, int64_t n_tx, int64_t n_classes, hipStream_t stream);
+// fresh control block; replicates n_live .. EM_BATCH-1 are unused and count as stopped
+void launch_em_batch_ctl(unsigned long long *ctl, int n_live, hipStream_t stream);
 // out[r][t], r < n_out: the replicates' results once everything queued has run
 void launch_em_batch_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n_tx,
                             int n_out, double *out, hipStream_t stream);
 
-// device-side construction of the two CSR views (hipCUB sorts/scans + small kernels)
+// device-side construction of the two CSR views (skm_quant_setup.hip)
 struct QuantBuild {
     int64_t n_tx, n_classes, n_ids;
     int64_t *cls_offset;          // [C+1] out
@@ -202,11 +209,12 @@ struct QuantBuild {
     int64_t *row_start;           // [R+1] out (capacity n_rows_cap + 1)
     int32_t *row_tx;              // [R]   out
     int64_t n_rows_cap;
-    int first_seen_bits;          // significant bits of the table's first-seen values (sort width)
+    int64_t first_seen_bound;     // every first-seen value of the table is below this (0: unknown)
 };
-// One asynchronous pipeline: (classes from a mapper's table in first-seen order when `table` is
-// given) -> stable reorder by smallest transcript id (gather locality; perm[k] = caller's index of
-// internal class k) -> transcript-major rows.  Returns the number of rows, or < 0.
+// One asynchronous pipeline: classes (from a mapper's table when `table` is given, the caller's
+// order being first-seen order) in (smallest transcript id, caller's index) order for gather
+// locality, perm[k] = caller's index of internal class k -> transcript-major rows.  Returns the
+// number of rows, or < 0.
 int64_t quant_setup(const ClassTable *table, QuantBuild &q, int32_t *perm, hipStream_t stream);
 // y[k] = x[perm[k]] (gather) or y[perm[k]] = x[k] (scatter), n doubles
 void launch_permute_f64(const double *x, const int32_t *perm, int64_t n, double *y, bool scatter,

@@ -1,13 +1,21 @@
-// Device-side construction of the EM problem: the class-major CSR in the
-// reference's class order (ascending first-seen unit = collections.Counter
-// insertion order under -j1, /root/reference/seekmer/mapper.py:88) and its
-// transcript-major transpose cut into rows.  Library primitives (hipCUB radix
-// sort and scan) do the ordering; the small kernels here only move indices.
-// One-time setup per quantification, not part of the per-step hot loop.
+// Device-side construction of the EM problem: the class-major CSR and its
+// transcript-major transpose cut into rows.  The caller's class order is the
+// reference's (ascending first-seen unit = collections.Counter insertion order
+// under -j1, /root/reference/seekmer/mapper.py:88); internally the classes are
+// kept in (smallest transcript id, first-seen) order for gather locality, with
+// perm[] leading back to the caller's order.
+//
+// From a mapper's table the first-seen RANK of every class comes from a bitmap
+// over the unit indices (first-seen values are distinct: a unit belongs to one
+// class) and a prefix popcount -- no sort; one stable 18-bit radix sort of the
+// classes by smallest id and one of the pairs by transcript remain (rocPRIM's
+// onesweep), everything else is small index-moving kernels.  One-time setup per
+// quantification, not part of the per-step hot loop.
 #include "skm_kernels.h"
 #include "skm_pool.h"
 
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 #include <vector>
 
 namespace skm {
@@ -47,18 +55,96 @@ iota_kernel(int32_t *out, int64_t n)
 }
 
 // dump of the table in registry order: arena offset, length, count, first-seen per class
+// (+ the class's smallest transcript id, the locality key, when asked for)
 __global__ void __launch_bounds__(256)
 table_dump_kernel(ClassTable t, int64_t n_classes, int64_t *arena_off, int64_t *len, double *count,
-                  unsigned long long *first_seen)
+                  unsigned long long *first_seen, uint32_t *min_id)
 {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_classes;
          k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t.class_list[k];
         const ClassSlot s = t.slots[i];
-        arena_off[k] = s.tuple < 0 ? -1 : tuple_offset(s.tuple);
-        len[k] = s.tuple < 0 ? 0 : tuple_len(s.tuple);
+        const int64_t off = s.tuple < 0 ? -1 : tuple_offset(s.tuple);
+        const int64_t n = s.tuple < 0 ? 0 : tuple_len(s.tuple);
+        arena_off[k] = off;
+        len[k] = n;
         count[k] = (double)s.count;
         first_seen[k] = s.first_seen;
+        if (min_id) {
+            uint32_t m = 0xffffffffu;
+            for (int64_t j = 0; j < n; ++j) m = min(m, (uint32_t)t.arena[off + j]);
+            min_id[k] = m;
+        }
+    }
+}
+
+// ---- first-seen ranks from a bitmap over the unit indices
+// one bit per unit index; a bit found set already means two classes share a first-seen value
+// (possible only for tables merged from hand-made input): *duplicate is raised and the caller
+// takes the sorting path instead
+__global__ void __launch_bounds__(256)
+mark_first_seen_kernel(const unsigned long long *first_seen, int64_t n_classes, uint64_t bound,
+                       uint32_t *bits, unsigned int *duplicate)
+{
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_classes;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long f = first_seen[k];
+        if (f >= bound) { atomicOr(duplicate, 2u); continue; }
+        const uint32_t bit = 1u << (f & 31);
+        if (atomicOr(&bits[f >> 5], bit) & bit) atomicOr(duplicate, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+word_popcount_kernel(const uint32_t *bits, int64_t n_words, int64_t *count)
+{
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n_words;
+         w += (int64_t)gridDim.x * blockDim.x) count[w] = __popc(bits[w]);
+}
+
+// rank r of class k = set bits below its own; by_rank[r] = k, key_by_rank[r] = its locality key
+__global__ void __launch_bounds__(256)
+first_seen_rank_kernel(const unsigned long long *first_seen, const uint32_t *min_id, int64_t n_classes,
+                       uint64_t bound, const uint32_t *bits, const int64_t *word_base, int32_t *by_rank,
+                       uint32_t *key_by_rank)
+{
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n_classes;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long f = first_seen[k];
+        if (f >= bound) continue;
+        const int64_t r = word_base[f >> 5] + __popc(bits[f >> 5] & ((1u << (f & 31)) - 1u));
+        if (r >= n_classes) continue;             // (only after a duplicate; the result is discarded)
+        by_rank[r] = (int32_t)k;
+        key_by_rank[r] = min_id[k];
+    }
+}
+
+// internal class j = the class of first-seen rank perm[j] = registry entry by_rank[perm[j]]
+__global__ void __launch_bounds__(256)
+gather_by_rank_kernel(const int32_t *perm, const int32_t *by_rank, int64_t n, const int64_t *len_in,
+                      const double *count_in, const int64_t *arena_off_in, int64_t *len_out,
+                      double *count_out, int64_t *arena_off_out)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t k = by_rank[perm[j]];
+        len_out[j] = len_in[k];
+        count_out[j] = count_in[k];
+        arena_off_out[j] = arena_off_in[k];
+    }
+}
+
+// ids of internal class j <- arena[src_off[j] ...]
+__global__ void __launch_bounds__(256)
+copy_tuples_direct_kernel(int64_t n, const int64_t *src_off, const int32_t *arena, const int64_t *cls_offset,
+                          int32_t *ids)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = src_off[j];
+        const int64_t dst = cls_offset[j];
+        const int64_t len = cls_offset[j + 1] - dst;
+        for (int64_t i = 0; i < len; ++i) ids[dst + i] = arena[src + i];
     }
 }
 
@@ -199,16 +285,21 @@ int exclusive_scan_with_total(Scratch &scratch, const int64_t *in, int64_t *out,
     return 0;
 }
 
+// Stable radix sort of (key, value) pairs on bits [0, end_bit).  Onesweep at every size: below
+// 1 M items rocPRIM's default picks its merge sort, which at the 0.85 M classes of configs[1]
+// takes ten merge rounds (155 us) where three onesweep passes take a third of that.
+using OnesweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 0>;
 template <class K>
 int sort_pairs(Scratch &scratch, const K *keys_in, K *keys_out, const int32_t *vals_in, int32_t *vals_out,
                int64_t n, int end_bit)
 {
     size_t bytes = 0;
-    QB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0,
-                                             end_bit, scratch.stream));
+    QB_TRY(rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, bytes, keys_in, keys_out, vals_in, vals_out,
+                                                     (size_t)n, 0u, (unsigned)end_bit, scratch.stream));
     QB_ALLOC(tmp, char, bytes);
-    QB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0,
-                                             end_bit, scratch.stream));
+    QB_TRY(rocprim::radix_sort_pairs<OnesweepAlways>(tmp, bytes, keys_in, keys_out, vals_in, vals_out,
+                                                     (size_t)n, 0u, (unsigned)end_bit, scratch.stream));
     return 0;
 }
 
@@ -256,15 +347,71 @@ int build_from_table(Scratch &scratch, const ClassTable &t, QuantBuild &q)
     QB_ALLOC(first, unsigned long long, n_classes); QB_ALLOC(first_sorted, unsigned long long, n_classes);
     QB_ALLOC(iota, int32_t, n_classes); QB_ALLOC(perm, int32_t, n_classes);
     hipLaunchKernelGGL(table_dump_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream,
-                       t, n_classes, arena_off, len, count, first);
+                       t, n_classes, arena_off, len, count, first, (uint32_t *)nullptr);
     hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, iota, n_classes);
-    const int first_bits = q.first_seen_bits > 0 && q.first_seen_bits < 64 ? q.first_seen_bits : 64;
+    int first_bits = 64;
+    if (q.first_seen_bound > 0) {
+        first_bits = 1;
+        while (first_bits < 63 && (1LL << first_bits) <= q.first_seen_bound) ++first_bits;
+    }
     if (sort_pairs(scratch, first, first_sorted, iota, perm, n_classes, first_bits)) return -1;
     hipLaunchKernelGGL(gather_classes_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm,
                        n_classes, len, count, len_sorted, q.cls_count);
     if (exclusive_scan_with_total(scratch, len_sorted, q.cls_offset, n_classes)) return -1;
     hipLaunchKernelGGL(copy_tuples_kernel, dim3(blocks_for(n_classes)), dim3(256), 0, stream, perm,
                        n_classes, arena_off, t.arena, q.cls_offset, q.ids);
+    return 0;
+}
+
+// The same result as build_from_table + localize (classes by smallest transcript id, then by
+// first-seen; perm[j] = first-seen rank of internal class j) with one sort instead of two and one
+// copy of the tuples instead of two: the first-seen rank is a prefix popcount over a bitmap of
+// the unit indices.  Returns 1 (nothing usable written) when two classes share a first-seen
+// value or one lies outside the bound: the caller falls back to the sorting path.
+constexpr int64_t RANK_BITMAP_MAX_UNITS = 1LL << 31;      // 256 MiB of bits + 4 GiB of word sums at most
+
+int build_from_table_ranked(Scratch &scratch, const ClassTable &t, QuantBuild &q, int32_t *perm)
+{
+    hipStream_t stream = scratch.stream;
+    const int64_t C = q.n_classes;
+    if (C == 0) {
+        QB_TRY(hipMemsetAsync(q.cls_offset, 0, sizeof(int64_t), stream));
+        return 0;
+    }
+    if (C >= (1LL << 31) || q.n_ids >= (1LL << 31)) return -2;
+    const uint64_t bound = (uint64_t)q.first_seen_bound;
+    const int64_t n_words = (int64_t)((bound + 31) / 32);
+    QB_ALLOC(arena_off, int64_t, C); QB_ALLOC(len, int64_t, C); QB_ALLOC(count, double, C);
+    QB_ALLOC(first, unsigned long long, C); QB_ALLOC(min_id, uint32_t, C);
+    QB_ALLOC(bits, uint32_t, n_words); QB_ALLOC(duplicate, unsigned int, 1);
+    QB_TRY(hipMemsetAsync(bits, 0, n_words * sizeof(uint32_t), stream));
+    QB_TRY(hipMemsetAsync(duplicate, 0, sizeof(unsigned int), stream));
+    hipLaunchKernelGGL(table_dump_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, t, C, arena_off, len, count,
+                       first, min_id);
+    hipLaunchKernelGGL(mark_first_seen_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, first, C, bound, bits,
+                       duplicate);
+    unsigned int shared_first_seen = 0;
+    QB_TRY(hipMemcpyAsync(&shared_first_seen, duplicate, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    QB_TRY(hipStreamSynchronize(stream));
+    if (shared_first_seen) return 1;
+
+    QB_ALLOC(word_count, int64_t, n_words); QB_ALLOC(word_base, int64_t, n_words + 1);
+    QB_ALLOC(by_rank, int32_t, C); QB_ALLOC(key_by_rank, uint32_t, C); QB_ALLOC(key_sorted, uint32_t, C);
+    QB_ALLOC(iota, int32_t, C); QB_ALLOC(len_sorted, int64_t, C); QB_ALLOC(src_off, int64_t, C);
+    hipLaunchKernelGGL(word_popcount_kernel, dim3(blocks_for(n_words)), dim3(256), 0, stream, bits, n_words,
+                       word_count);
+    if (exclusive_scan_with_total(scratch, word_count, word_base, n_words)) return -1;
+    hipLaunchKernelGGL(first_seen_rank_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, first, min_id, C, bound,
+                       bits, word_base, by_rank, key_by_rank);
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, iota, C);
+    int end_bit = 1;
+    while ((1LL << end_bit) < q.n_tx && end_bit < 32) ++end_bit;
+    if (sort_pairs(scratch, key_by_rank, key_sorted, iota, perm, C, end_bit)) return -1;
+    hipLaunchKernelGGL(gather_by_rank_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, perm, by_rank, C, len,
+                       count, arena_off, len_sorted, q.cls_count, src_off);
+    if (exclusive_scan_with_total(scratch, len_sorted, q.cls_offset, C)) return -1;
+    hipLaunchKernelGGL(copy_tuples_direct_kernel, dim3(blocks_for(C)), dim3(256), 0, stream, C, src_off, t.arena,
+                       q.cls_offset, q.ids);
     return 0;
 }
 
@@ -326,23 +473,33 @@ int transpose(Scratch &scratch, QuantBuild &q)
 
 }  // namespace
 
-// The whole setup as one asynchronous pipeline on `stream`: (classes from the
-// mapper's table in first-seen order, when `table` is given) -> locality order
-// -> transcript-major rows.  One synchronisation at the end; returns the number
-// of rows or a negative code.
+// The whole setup as one asynchronous pipeline on `stream`: classes from the mapper's table (when
+// `table` is given) in locality order with perm[] back to first-seen order -- ranked by bitmap
+// when the first-seen values allow it, by two sorts otherwise -- or the caller's classes
+// reordered; then the transcript-major rows.  Returns the number of rows or a negative code.
 int64_t quant_setup(const ClassTable *table, QuantBuild &q, int32_t *perm, hipStream_t stream)
 {
-    int64_t n_rows = -1;
-    {
-        Scratch scratch(stream);
-        if (table && build_from_table(scratch, *table, q)) return -1;
-        if (localize(scratch, q, perm)) return -1;
-        if (transpose(scratch, q)) return -1;
-        QB_TRY(hipGetLastError());
-        QB_TRY(hipMemcpyAsync(&n_rows, q.tx_row + q.n_tx, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    }                                  // ~Scratch: the single synchronisation
-    if (n_rows > q.n_rows_cap) return -3;
-    return n_rows;
+    const bool can_rank = table && q.first_seen_bound > 0 && q.first_seen_bound <= RANK_BITMAP_MAX_UNITS;
+    for (int attempt = can_rank ? 0 : 1; attempt < 2; ++attempt) {
+        int64_t n_rows = -1;
+        {
+            Scratch scratch(stream);
+            if (attempt == 0) {
+                const int rc = build_from_table_ranked(scratch, *table, q, perm);
+                if (rc == 1) continue;
+                if (rc) return -1;
+            } else {
+                if (table && build_from_table(scratch, *table, q)) return -1;
+                if (localize(scratch, q, perm)) return -1;
+            }
+            if (transpose(scratch, q)) return -1;
+            QB_TRY(hipGetLastError());
+            QB_TRY(hipMemcpyAsync(&n_rows, q.tx_row + q.n_tx, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        }                              // ~Scratch: the synchronisation
+        if (n_rows > q.n_rows_cap) return -3;
+        return n_rows;
+    }
+    return -1;
 }
 
 }  // namespace skm

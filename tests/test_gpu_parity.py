@@ -399,6 +399,44 @@ def test_em_device_table_path_and_determinism(oracle, native_libs):
     np.testing.assert_allclose(x_dev, x_ref, rtol=1e-9, atol=1e-300)
 
 
+def test_class_views_when_first_seen_values_are_shared(oracle, native_libs):
+    """The class views are ordered through a bitmap of the first-seen unit indices, which needs
+    them distinct (they are, for tables the mapper filled: a unit belongs to one class).  A table
+    merged from hand-made input may share them: the build then falls back to its sorting path.
+    Same classes, same counts, EM to 1e-9 of the host path on the merged table's own export."""
+    from seekmer_amd import synth, index_builder, infer, mapper
+    ids, pool, tx_offsets = synth.transcriptome(8, 40)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    n_units = 20000
+    bases, offsets = synth.reads(8, pool, tx_offsets, 0, n_units, 100, True)
+    result, _ = _run_gpu(index, bases, offsets, n_units, True)
+    offs, targets, counts, first, fld = result.export()
+    assert np.unique(first).size == first.size
+    merged = mapper.MapResult(index)
+    merged.merge_table(offs, targets, counts, first // 3, result.sizes()[2], fld)
+    m_offs, m_targets, m_counts, m_first, _ = merged.export()
+    assert np.unique(m_first).size < m_first.size and (np.diff(m_first) >= 0).all()
+    as_set = lambda o, t, c: sorted((tuple(t[o[k]:o[k + 1]]), int(c[k])) for k in range(c.size))
+    assert as_set(m_offs, m_targets, m_counts) == as_set(offs, targets, counts)
+    summarized = merged.summarize()
+    eff = summarized.effective_lengths
+    x0 = np.ones(eff.size) / eff
+    x0 /= x0.sum()
+    quant = infer._QuantHandle.from_map_result(merged, eff.size)
+    x_dev, it_dev = quant.em(x0, eff)
+    x_again, it_again = quant.em(x0, eff)
+    quant.close()
+    np.testing.assert_array_equal(x_dev, x_again)
+    x_host, it_host = infer.em(x0, eff, summarized.class_map, summarized.class_count, return_iters=True)
+    assert abs(it_host - it_dev) <= 1 and it_again == it_dev
+    np.testing.assert_allclose(x_dev, x_host, rtol=1e-6 if it_host != it_dev else 1e-9, atol=1e-300)
+    # and the table the mapper filled itself (distinct values: the bitmap path) gives the same EM
+    quant = infer._QuantHandle.from_map_result(result, eff.size)
+    x_own, _ = quant.em(x0, eff)
+    quant.close()
+    np.testing.assert_allclose(x_own, x_dev, rtol=1e-6 if it_host != it_dev else 1e-9, atol=1e-300)
+
+
 def test_em_skewed_and_degenerate_tables(oracle, native_libs):
     """A transcript in thousands of classes (several 512-entry rows), duplicate
     ids inside a tuple, transcripts in no class, zero counts (bootstrap), and
@@ -465,7 +503,7 @@ def _check_multinomial_dispersion(counts, class_count):
     assert abs(cov + n * p[i] * p[j]) < 6 * sd * np.sqrt(2)
 
 
-def test_bootstrap_draw_and_em(oracle, native_libs):
+def test_bootstrap_draw_and_em(oracle, native_libs, monkeypatch):
     """The multinomial draw is only distributional (the reference draws from
     numpy's unseeded generator): totals exact, mean n*p within 6 sigma; the EM
     from the drawn counts equals the oracle EM on the same counts."""
@@ -489,6 +527,18 @@ def test_bootstrap_draw_and_em(oracle, native_libs):
     # (skm_em_batch.hip): the same draws, the same additions -- the same bits and step counts
     out8, _, iters8 = quant.bootstrap(n_boot, 1234, x0, l)
     out5, _, iters5 = quant.bootstrap(5, 1234, x0, l)             # (a short last group)
+    # replicates still running after their group's budget of steps go on together in a second
+    # working set: with the budget pinned low every replicate takes that way (groups of eight
+    # late ones, a short last one, results routed to their places) -- the same bits again
+    tpm8, _, _ = quant.bootstrap(n_boot, 1234, x0, l, tpm=True)
+    for budget, n in (('1', n_boot), ('3', 21), ('7', n_boot)):
+        monkeypatch.setenv('SKM_BOOTSTRAP_BUDGET', budget)
+        late, _, iters_late = quant.bootstrap(n, 1234, x0, l)
+        np.testing.assert_array_equal(late, out[:n])
+        np.testing.assert_array_equal(iters_late, iters[:n])
+        late_tpm, _, _ = quant.bootstrap(n, 1234, x0, l, tpm=True)
+        np.testing.assert_array_equal(late_tpm, tpm8[:n])
+    monkeypatch.delenv('SKM_BOOTSTRAP_BUDGET')
     quant.close()
     np.testing.assert_array_equal(counts, counts2)      # seeded: reproducible
     np.testing.assert_array_equal(out, out2)
@@ -510,7 +560,7 @@ def test_bootstrap_draw_and_em(oracle, native_libs):
         np.testing.assert_allclose(out[b], x_ref, rtol=1e-8, atol=1e-300)
 
 
-def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs):
+def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs, monkeypatch):
     """BASELINE.json configs[4] in shape (paired 2x100 reads mapped on the GPU, then `-b 100`,
     seekmer/infer.py:79-82, 108-111) at a size the oracle EM still handles: 1.2 M pairs are
     mapped, the class table stays in HBM, skm_quant_bootstrap draws 100 resamples from it.
@@ -537,6 +587,11 @@ def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs):
     out8, _, iters8 = quant.bootstrap(n_boot, 20240, x0, eff)    # batched EM: bit for bit the same
     np.testing.assert_array_equal(out8, out)
     np.testing.assert_array_equal(iters8, iters)
+    monkeypatch.setenv('SKM_BOOTSTRAP_BUDGET', str(max(2, int(np.median(iters)) - 3)))
+    out_late, _, iters_late = quant.bootstrap(n_boot, 20240, x0, eff)   # about half of them finish late
+    monkeypatch.delenv('SKM_BOOTSTRAP_BUDGET')
+    np.testing.assert_array_equal(out_late, out)
+    np.testing.assert_array_equal(iters_late, iters)
     # the handle holds the observed counts again afterwards
     x_main, it_main = quant.em(1.0 / eff / (1.0 / eff).sum(), eff)
     quant.close()
