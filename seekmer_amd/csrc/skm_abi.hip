@@ -196,9 +196,6 @@ struct skm_quant {
         DBuf<double> cls_count, inner, row_sum, x0, x1, part_max;
         DBuf<unsigned int> part_flags;
         DBuf<unsigned long long> ctl;
-        // replicates still running when their group's budget of steps is spent go on together here
-        DBuf<double> late_count, late_x0, late_x1, late_out;
-        DBuf<unsigned long long> late_ctl;
     } batch;
     double n_total = 0;
     bool n_total_reduced = false;             // n_total already is the sum over all ranks
@@ -1666,8 +1663,6 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->cum.release(); q->tile_total.release(); q->x_start.release(); q->boot_out.release();
     q->batch.cls_count.release(); q->batch.inner.release(); q->batch.row_sum.release(); q->batch.x0.release();
     q->batch.x1.release(); q->batch.part_max.release(); q->batch.part_flags.release(); q->batch.ctl.release();
-    q->batch.late_count.release(); q->batch.late_x0.release(); q->batch.late_x1.release();
-    q->batch.late_out.release(); q->batch.late_ctl.release();
     for (auto &e : q->ev) pool_event_release(e, true);
     for (auto &e : q->chunk_ev) pool_event_release(e, false);
     pool_pinned_release(q->pinned);
@@ -1794,31 +1789,25 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
         HIP_TRY(hipStreamSynchronize(q->stream));
         return SKM_OK;
     };
-    // The first replicate goes the careful way and tells how many EM steps a replicate of this
-    // table takes.  So does every replicate when the resampled counts are wanted, a step cap is
-    // set, or a communicator is attached (its collectives must stay matched).  Otherwise the rest
-    // run EM_BATCH at a time through the batched EM: all draws, a budget of steps whose kernels
-    // turn into no-ops once every replicate's stopping rule has latched on the device, results
-    // picked on the device -- one host round trip per eight replicates.  A replicate that has not
-    // latched within the budget (step counts have a long tail: most replicates of the 20 M-pair
-    // table stop near 30 steps, one in six needs 60-90) moves, as it stands, into a second working
-    // set where up to eight such replicates of different groups go on together, in host-checked
-    // chunks.  Either way every replicate runs the single-problem EM's steps bit for bit.
-    int64_t first_steps = 0;
-    if (n_boot > 0) {
-        SKM_TRY(replicate_checked(0, &first_steps, q->boot_out.p));
-        SKM_TRY(send_home(0, 1));
-    }
+    // With the resampled counts wanted, a step cap set or a communicator attached (its collectives
+    // must stay matched) every replicate goes the careful way.  Otherwise EM_BATCH replicates sit side
+    // by side in the batched EM (skm_em_batch.hip) and the working set is kept full: steps are queued
+    // in short chunks; after each chunk the host reads which replicates have latched their stopping
+    // rule, takes their results, and puts the next replicates (fresh draw, the common start vector)
+    // in their places -- the others run on undisturbed.  Step counts have a long tail (most
+    // replicates of the 20 M-pair table stop near 30 steps, one in six needs 60-90): replicates
+    // that wait for the slowest of a fixed group of eight waste half the working set's steps.
+    // Every replicate still runs the single-problem EM's steps bit for bit, whoever its neighbours are.
     const bool batched = !counts_out && !q->comm && max_iters <= 0;
     if (!batched) {
-        for (int64_t b = 1; b < n_boot; ++b) {
+        for (int64_t b = 0; b < n_boot; ++b) {
             int64_t it = 0;
             SKM_TRY(replicate_checked(b, &it, q->boot_out.p));
             SKM_TRY(send_home(b, 1));
         }
         return rc;
     }
-    const int64_t slots = std::max<int64_t>(EM_BATCH, group / EM_BATCH * EM_BATCH);
+    const int64_t slots = std::max<int64_t>(1, group);
     SKM_TRY(q->boot_out.ensure((size_t)(slots * T)));
     skm_quant::Batch &w = q->batch;
     SKM_TRY(w.cls_count.ensure((size_t)C * EM_BATCH)); SKM_TRY(w.inner.ensure((size_t)C * EM_BATCH));
@@ -1835,118 +1824,58 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     p.x[0] = w.x0.p; p.x[1] = w.x1.p;
     p.n_total = (double)n_draws; p.rel_tol = rel_tol; p.x_floor = x_floor;
     p.ctl = w.ctl.p; p.part_max = w.part_max.p; p.part_flags = w.part_flags.p;
-    SKM_TRY(w.late_count.ensure((size_t)C * EM_BATCH)); SKM_TRY(w.late_x0.ensure((size_t)T * EM_BATCH));
-    SKM_TRY(w.late_x1.ensure((size_t)T * EM_BATCH)); SKM_TRY(w.late_out.ensure((size_t)T * EM_BATCH));
-    SKM_TRY(w.late_ctl.ensure(32));
-    EmBatchProblem late = p;                  // (inner, row_sum and the partials are per-step scratch: shared)
-    late.cls_count = w.late_count.p; late.x[0] = w.late_x0.p; late.x[1] = w.late_x1.p; late.ctl = w.late_ctl.p;
-    // Steps queued blind per group: where three quarters of the replicates seen so far had stopped,
-    // plus two (the first group only knows the first replicate).  SKM_BOOTSTRAP_BUDGET pins it (tests).
-    std::vector<int64_t> seen_steps{first_steps};
-    const char *pinned_budget = getenv("SKM_BOOTSTRAP_BUDGET");
-    auto next_budget = [&]() -> int64_t {
-        if (pinned_budget && atoll(pinned_budget) > 0) return atoll(pinned_budget);
-        std::vector<int64_t> v(seen_steps);
-        std::sort(v.begin(), v.end());
-        return std::max<int64_t>(4, v[3 * (v.size() - 1) / 4] + 2);
-    };
+    int64_t chunk = 6;                                           // steps between two looks at the working set
+    if (const char *e = getenv("SKM_BOOTSTRAP_CHUNK")) chunk = std::max<int64_t>(1, atoll(e));   // (tests)
     unsigned long long *const verdict = q->pinned + 64;          // 32 words of the pinned block
-    int64_t late_of[EM_BATCH], late_base[EM_BATCH];              // the replicates waiting in the second set, and
-    int n_late = 0;                                              // the steps each had done when it moved there
-    int64_t filled = 0, first_held = 1;                          // boot_out holds replicates first_held ..
-    // the waiting replicates go on (their step 0 here = step late_base of their own) until the last has
-    // stopped, in host-checked chunks; results to their place in boot_out, or straight home
-    auto finish_late = [&]() -> int {
-        if (n_late == 0) return SKM_OK;
-        launch_em_batch_ctl(late.ctl, n_late, q->stream);
-        int64_t k = 0;
-        for (;;) {
-            const int64_t chunk = 8;
-            for (int64_t i = 0; i < chunk; ++i, ++k) launch_em_batch_step(late, k, q->stream);
-            launch_em_batch_decide(late, k, q->stream);
-            q->launches += 3 * chunk + 1;
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(verdict, late.ctl, 32 * 8, hipMemcpyDeviceToHost, q->stream));
-            HIP_TRY(hipStreamSynchronize(q->stream));
-            if (verdict[0]) break;
-        }
-        launch_em_batch_result(late.ctl, late.x[0], late.x[1], T, n_late, w.late_out.p, q->stream);
-        HIP_TRY(hipGetLastError());
-        for (int r = 0; r < n_late; ++r) {
-            if (verdict[24 + r])
-                return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
-            const int64_t steps = late_base[r] + (int64_t)verdict[16 + r];
-            if (iters_out) iters_out[late_of[r]] = steps;
-            q->iters_total += (double)steps;
-            seen_steps.push_back(steps);
-            double *const result = w.late_out.p + (int64_t)r * T;
-            if (late_of[r] >= first_held) {      // its group has not gone home yet: into its place there
-                HIP_TRY(hipMemcpyAsync(q->boot_out.p + (late_of[r] - first_held) * T, result, (size_t)T * 8,
-                                       hipMemcpyDeviceToDevice, q->stream));
-            } else {
-                SKM_TRY(scale(result, 1));
-                HIP_TRY(hipMemcpyAsync(out + late_of[r] * T, result, (size_t)T * 8, hipMemcpyDeviceToHost, q->stream));
-            }
-        }
-        HIP_TRY(hipStreamSynchronize(q->stream));
-        n_late = 0;
-        return SKM_OK;
-    };
-    for (int64_t g0 = 1; g0 < n_boot; g0 += EM_BATCH) {
-        const int n_here = (int)std::min<int64_t>(EM_BATCH, n_boot - g0);
-        const int64_t budget = next_budget();
-        for (int r = 0; r < n_here; ++r)
-            if (!launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)(g0 + r), q->tile_total.p,
+    // the results of `slots` replicates at a time collect in boot_out and go home together
+    for (int64_t w0 = 0; w0 < n_boot; w0 += slots) {
+        const int64_t w1 = std::min(n_boot, w0 + slots);
+        int64_t place[EM_BATCH], since[EM_BATCH];                // the replicate in each place (-1: none), its first step
+        int64_t next = w0, k = 0;                                // next replicate to start; steps queued so far
+        unsigned int idle = 0;
+        auto start = [&](int r) -> int {                         // replicate `next` into place r, from step k on
+            if (!launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)next, q->tile_total.p,
                                     w.cls_count.p + r, EM_BATCH, q->stream))
                 return fail(SKM_ERR_STATE, "class table too large to resample (%lld classes)", (long long)C);
-        launch_em_batch_start(q->x_start.p, T, w.x0.p, q->stream);
-        launch_em_batch_ctl(w.ctl.p, n_here, q->stream);         // (the spare replicates of a short last group: stopped)
-        for (int64_t k = 0; k < budget; ++k) launch_em_batch_step(p, k, q->stream);
-        launch_em_batch_decide(p, budget, q->stream);
-        q->launches += 3 * budget + 1;
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(verdict, w.ctl.p, 32 * 8, hipMemcpyDeviceToHost, q->stream));
-        HIP_TRY(hipStreamSynchronize(q->stream));
-        const bool all_stopped = verdict[0] != 0;
-        bool held_back[EM_BATCH] = {};
-        for (int r = 0; r < n_here; ++r) {
-            if (verdict[24 + r])
-                return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
-            if (!verdict[8 + r]) {               // over budget: it goes on in the second working set
-                held_back[r] = true;
-            } else {
-                if (iters_out) iters_out[g0 + r] = (int64_t)verdict[16 + r];
-                q->iters_total += (double)verdict[16 + r];
-                seen_steps.push_back((int64_t)verdict[16 + r]);
+            launch_em_batch_place(q->x_start.p, T, r, p.x[k & 1], p.part_max, p.part_flags, q->stream);
+            place[r] = next++;
+            since[r] = k;
+            return SKM_OK;
+        };
+        for (int r = 0; r < EM_BATCH; ++r) {
+            place[r] = -1;
+            if (next < w1) SKM_TRY(start(r)); else idle |= 1u << r;
+        }
+        launch_em_batch_ctl(w.ctl.p, idle, q->stream);
+        for (;;) {
+            for (int64_t i = 0; i < chunk; ++i) launch_em_batch_step(p, k + i, q->stream);
+            launch_em_batch_decide(p, k + chunk, q->stream);
+            q->launches += 3 * chunk + 1;
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(verdict, w.ctl.p, 32 * 8, hipMemcpyDeviceToHost, q->stream));
+            HIP_TRY(hipStreamSynchronize(q->stream));
+            // (all stopped before the chunk's end: the steps after that one did nothing)
+            k = verdict[0] ? (int64_t)verdict[1] : k + chunk;
+            bool any = false;
+            for (int r = 0; r < EM_BATCH; ++r) {
+                if (place[r] < 0) continue;
+                if (!verdict[8 + r]) { any = true; continue; }
+                if (verdict[24 + r])
+                    return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
+                const int64_t steps = (int64_t)verdict[16 + r] - since[r];
+                if (iters_out) iters_out[place[r]] = steps;
+                q->iters_total += (double)steps;
+                // a stopped replicate is carried from buffer to buffer: the one step k would read holds it
+                launch_em_batch_take(p.x[k & 1], T, r, q->boot_out.p + (place[r] - w0) * T, q->stream);
+                place[r] = -1;
+                if (next < w1) { SKM_TRY(start(r)); any = true; } else idle |= 1u << r;
             }
+            HIP_TRY(hipGetLastError());
+            if (!any) break;
+            launch_em_batch_ctl(w.ctl.p, idle, q->stream);
         }
-        if (all_stopped) {
-            launch_em_batch_result(w.ctl.p, w.x0.p, w.x1.p, T, n_here, q->boot_out.p + filled * T, q->stream);
-        } else {
-            // not every replicate has stopped, so all `budget` steps ran: the current abundances of
-            // every replicate (the stopped ones carried along) are in buffer budget & 1
-            const double *const now = (budget & 1) ? w.x1.p : w.x0.p;
-            launch_em_batch_result(nullptr, now, now, T, n_here, q->boot_out.p + filled * T, q->stream);
-            for (int r = 0; r < n_here; ++r) {
-                if (!held_back[r]) continue;
-                launch_em_batch_move(now, w.cls_count.p, r, late.x[0], w.late_count.p, n_late, T, C, q->stream);
-                late_of[n_late] = g0 + r;
-                late_base[n_late++] = budget;
-                if (n_late == EM_BATCH) {
-                    HIP_TRY(hipGetLastError());
-                    SKM_TRY(finish_late());
-                }
-            }
-        }
-        HIP_TRY(hipGetLastError());
-        filled += n_here;
-        if (filled + EM_BATCH > slots || g0 + EM_BATCH >= n_boot) {
-            SKM_TRY(send_home(first_held, filled));          // (a replicate still waiting: sent again when it is done)
-            first_held += filled;
-            filled = 0;
-        }
+        SKM_TRY(send_home(w0, w1 - w0));
     }
-    SKM_TRY(finish_late());
     return rc;
 }
 

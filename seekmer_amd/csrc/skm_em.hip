@@ -286,9 +286,8 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 // over the integer cumulative counts, in two stages so that every draw is decided and counted
 // in LDS: the classes are cut into tiles of `tile` classes (at most MN_TILES tiles, at most
 // MN_TILES classes each);
-//   stage 1  n draws r ~ U[0, total) choose a TILE (binary search in the tiles' cumulative masses,
-//            LDS counters, one global add per tile and workgroup): the tile totals are
-//            multinomial(n, tile masses);
+//   stage 1  n draws r ~ U[0, total) choose a TILE (LDS counters, one global add per tile and
+//            workgroup): the tile totals are multinomial(n, tile masses);
 //   stage 2  one workgroup per tile makes its tile's m draws among the tile's classes
 //            (cumulative counts relative to the tile in LDS, LDS counters) and writes the counts.
 // n iid draws sorted into tiles and then, given the tile totals, iid within the tiles under the
@@ -297,42 +296,101 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 // and one device-scope atomic per draw was 1.45 ms for 20 M draws over 1 M classes: the
 // scattered atomics alone are bound at ~20 G/s.)  Counter-based generator: the reference draws
 // from numpy's unseeded global generator, so only the distribution can be matched.
+//
+// A draw costs what its arithmetic costs (20 M draws are ~100 G integer multiplies when every
+// draw takes its own 64-bit hash and a 64 x 64 multiply-high; 32-bit multiplies issue at a
+// quarter of the rate), so: one 64-bit hash serves TWO draws, each an exactly uniform integer
+// below the range from 32 bits by multiply-high with rejection (Lemire; rejected with
+// probability range / 2^32, then redrawn from a stream of its own), and the interval holding r
+// is found from a guide table over power-of-two buckets of r (one LDS read, then 1-2 steps
+// forward) instead of a 12-step binary search.
 constexpr int MN_TILES = 4096;
+constexpr int MN_GUIDE_BITS = 12;
 
-__device__ __forceinline__ uint64_t mn_uniform(uint64_t seed, uint64_t stream_id, uint64_t lane_id, uint64_t d,
-                                               unsigned long long range)
+struct MnStream {
+    uint64_t base, spare;      // counter-mode keys of the paired draws and of the redraws
+    uint64_t redraws;
+    __device__ __forceinline__ MnStream(uint64_t seed, uint64_t stream_id, uint64_t part)
+    {
+        base = mix64(seed ^ (stream_id * 0x9E3779B97F4A7C15ULL) ^ (part * 0xC2B2AE3D27D4EB4FULL));
+        spare = mix64(base ^ 0xA0761D6478BD642FULL);
+        redraws = 0;
+    }
+    // the two 32-bit words of draw pair number `pair`
+    __device__ __forceinline__ uint64_t words(uint64_t pair) const { return mix64(base + pair * 0xD1342543DE82EF95ULL); }
+};
+// exactly uniform in [0, range), range >= 1, from 32 random bits; `reject_below` = 2^32 mod range.
+// A rejected word is replaced from the lane's own redraw stream (pair number and lane identify it).
+__device__ __forceinline__ uint32_t mn_bounded(uint32_t word, uint32_t range, uint32_t reject_below, MnStream &rng,
+                                               uint64_t pair)
 {
-    const uint64_t bits = mix64(mix64(seed ^ (stream_id * 0x9E3779B97F4A7C15ULL) ^ (lane_id * 0xC2B2AE3D27D4EB4FULL))
-                                + d * 0xD1342543DE82EF95ULL);
-    return __umul64hi(bits, range);          // in [0, range)
+    uint64_t m = (uint64_t)word * range;
+    while ((uint32_t)m < reject_below) {
+        const uint64_t again = mix64(rng.spare + pair * 0xD1342543DE82EF95ULL + (++rng.redraws) * 0x9FB21C651E98DF25ULL);
+        m = (uint64_t)(uint32_t)(again >> 32) * range;
+    }
+    return (uint32_t)(m >> 32);
 }
 
-// first index in [0, n) with cum[index] > r (cum ascending, cum[n - 1] > r)
-__device__ __forceinline__ int mn_search(const unsigned long long *cum, int n, unsigned long long r)
-{
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cum[mid] > r) hi = mid; else lo = mid + 1;
+// Interval search over ascending cumulative counts cum[0..n) (cum[n-1] = total > r): guide[g] =
+// first index whose cumulative count exceeds the smallest r of bucket g = r >> shift.
+struct MnGuide {
+    int shift;
+    __device__ __forceinline__ static int shift_for(uint32_t total)
+    {
+        const int bits = 32 - __clz(total - 1 | 1u);                 // total <= 2^bits
+        return max(0, bits - MN_GUIDE_BITS);
     }
-    return lo;
+};
+// every thread i < n fills the buckets whose smallest r lies in [cum[i-1], cum[i])
+__device__ __forceinline__ void mn_fill_guide(const uint32_t *cum, int n, int shift, uint16_t *guide)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t lo = i ? cum[i - 1] : 0u, hi = cum[i];
+        const uint32_t w = 1u << shift;
+        // buckets g with g * w in [lo, hi)
+        uint32_t g = (uint32_t)(((uint64_t)lo + w - 1) >> shift);
+        const uint32_t g_end = (uint32_t)(((uint64_t)hi + w - 1) >> shift);
+        for (; g < g_end; ++g) guide[g] = (uint16_t)i;
+    }
+}
+__device__ __forceinline__ int mn_find(const uint32_t *cum, const uint16_t *guide, int shift, uint32_t r)
+{
+    int i = guide[r >> shift];
+    while (cum[i] <= r) ++i;
+    return i;
 }
 
 __global__ void __launch_bounds__(1024)
 multinomial_tiles_kernel(const unsigned long long *__restrict__ cum, int64_t n_classes, int tile, int n_tiles,
                          int64_t n_draws, uint64_t seed, uint64_t stream_id, unsigned int *__restrict__ tile_total)
 {
-    __shared__ unsigned long long tile_cum[MN_TILES];
+    __shared__ uint32_t tile_cum[MN_TILES];
     __shared__ unsigned int count[MN_TILES];
+    __shared__ uint16_t guide[1 << MN_GUIDE_BITS];
     for (int k = threadIdx.x; k < n_tiles; k += blockDim.x) {
-        tile_cum[k] = cum[min(n_classes, (int64_t)(k + 1) * tile) - 1];
+        tile_cum[k] = (uint32_t)cum[min(n_classes, (int64_t)(k + 1) * tile) - 1];     // (total < 2^32: checked by the caller)
         count[k] = 0;
     }
     __syncthreads();
-    const unsigned long long total = tile_cum[n_tiles - 1];
-    const int64_t first = n_draws * blockIdx.x / gridDim.x, last = n_draws * (blockIdx.x + 1) / gridDim.x;
-    for (int64_t d = first + threadIdx.x; d < last; d += blockDim.x)
-        atomicAdd(&count[mn_search(tile_cum, n_tiles, mn_uniform(seed, stream_id, 0, (uint64_t)d, total))], 1u);
+    const uint32_t total = tile_cum[n_tiles - 1];
+    const int shift = MnGuide::shift_for(total);
+    mn_fill_guide(tile_cum, n_tiles, shift, guide);
+    __syncthreads();
+    const uint32_t reject_below = (uint32_t)(0u - total) % total;
+    MnStream rng(seed, stream_id, 0);
+    // draws 2p and 2p + 1 share hash number p; the workgroups split the pairs evenly
+    const int64_t n_pairs = (n_draws + 1) >> 1;
+    const int64_t first = n_pairs * blockIdx.x / gridDim.x, last = n_pairs * (blockIdx.x + 1) / gridDim.x;
+    for (int64_t p = first + threadIdx.x; p < last; p += blockDim.x) {
+        const uint64_t w = rng.words((uint64_t)p);
+        const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), total, reject_below, rng, (uint64_t)p);
+        atomicAdd(&count[mn_find(tile_cum, guide, shift, r0)], 1u);
+        if (2 * p + 1 < n_draws) {
+            const uint32_t r1 = mn_bounded((uint32_t)w, total, reject_below, rng, (uint64_t)p);
+            atomicAdd(&count[mn_find(tile_cum, guide, shift, r1)], 1u);
+        }
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < n_tiles; k += blockDim.x)
         if (count[k]) atomicAdd(&tile_total[k], count[k]);
@@ -344,21 +402,37 @@ multinomial_classes_kernel(const unsigned long long *__restrict__ cum, int64_t n
                            const unsigned int *__restrict__ tile_total, uint64_t seed, uint64_t stream_id,
                            double *__restrict__ counts, int stride)
 {
-    __shared__ unsigned long long local_cum[MN_TILES];
+    __shared__ uint32_t local_cum[MN_TILES];
     __shared__ unsigned int count[MN_TILES];
+    __shared__ uint16_t guide[1 << MN_GUIDE_BITS];
     const int64_t first_class = (int64_t)blockIdx.x * tile;
     const int n = (int)min((int64_t)tile, n_classes - first_class);
     const unsigned long long before = first_class ? cum[first_class - 1] : 0ULL;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        local_cum[i] = cum[first_class + i] - before;
+        local_cum[i] = (uint32_t)(cum[first_class + i] - before);
         count[i] = 0;
     }
     __syncthreads();
-    const unsigned long long mass = local_cum[n - 1];
+    const uint32_t mass = local_cum[n - 1];
     const unsigned int draws = tile_total[blockIdx.x];       // (0 when the tile has no mass)
-    for (unsigned int d = threadIdx.x; d < draws; d += blockDim.x)
-        atomicAdd(&count[mn_search(local_cum, n, mn_uniform(seed, stream_id, 1 + blockIdx.x, d, mass))], 1u);
-    __syncthreads();
+    if (draws) {                                             // (uniform over the workgroup)
+        const int shift = MnGuide::shift_for(mass);
+        mn_fill_guide(local_cum, n, shift, guide);
+        __syncthreads();
+        const uint32_t reject_below = (uint32_t)(0u - mass) % mass;
+        MnStream rng(seed, stream_id, 1 + blockIdx.x);
+        const unsigned int n_pairs = (draws + 1) >> 1;
+        for (unsigned int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
+            const uint64_t w = rng.words(p);
+            const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), mass, reject_below, rng, p);
+            atomicAdd(&count[mn_find(local_cum, guide, shift, r0)], 1u);
+            if (2 * p + 1 < draws) {
+                const uint32_t r1 = mn_bounded((uint32_t)w, mass, reject_below, rng, p);
+                atomicAdd(&count[mn_find(local_cum, guide, shift, r1)], 1u);
+            }
+        }
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) counts[(first_class + i) * stride] = (double)count[i];
 }
 
@@ -672,7 +746,7 @@ bool launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_
     const int n_tiles = (int)((n_classes + tile - 1) / tile);
     (void)hipMemsetAsync(tile_total, 0, MN_TILES * sizeof(unsigned int), stream);
     if (n_draws > 0)
-        hipLaunchKernelGGL(multinomial_tiles_kernel, dim3(256), dim3(1024), 0, stream, cum, n_classes, tile,
+        hipLaunchKernelGGL(multinomial_tiles_kernel, dim3(512), dim3(1024), 0, stream, cum, n_classes, tile,
                            n_tiles, n_draws, seed, stream_id, tile_total);
     hipLaunchKernelGGL(multinomial_classes_kernel, dim3((unsigned)n_tiles), dim3(1024), 0, stream, cum, n_classes,
                        tile, tile_total, seed, stream_id, counts, stride);

@@ -17,6 +17,8 @@
 // one-by-one run gives -- bit for bit (tests/test_gpu_parity.py::test_bootstrap_draw_and_em).
 #include "skm_kernels.h"
 
+#include <algorithm>
+
 namespace skm {
 
 namespace {
@@ -213,47 +215,33 @@ em_decide_batch_kernel(EmBatchProblem p, int n_parts, int64_t steps_done)
     evaluate_batch(p, n_parts, steps_done, true);
 }
 
-// x[t][r] = start[t]
+// a new replicate in place r: x[t][r] = start[t], and the partials of "the step before" say
+// "selected, changing" for it, so that whoever judges next leaves it running
 __global__ void __launch_bounds__(256)
-em_batch_start_kernel(const double *__restrict__ start, int64_t n_tx, double *__restrict__ x)
+em_batch_place_kernel(const double *__restrict__ start, int64_t n_tx, int r, double *__restrict__ x,
+                      double *__restrict__ part_max, unsigned int *__restrict__ part_flags)
 {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx * R;
-         i += (int64_t)gridDim.x * blockDim.x) x[i] = start[i / R];
-}
-
-// replicate `from` of one working set -> replicate `to` of another: its abundances (the buffer the
-// next step reads) and its counts
-__global__ void __launch_bounds__(256)
-em_batch_move_kernel(const double *__restrict__ x_from, const double *__restrict__ count_from, int from,
-                     double *__restrict__ x_to, double *__restrict__ count_to, int to, int64_t n_tx,
-                     int64_t n_classes)
-{
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx + n_classes;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        if (i < n_tx) x_to[i * R + to] = x_from[i * R + from];
-        else count_to[(i - n_tx) * R + to] = count_from[(i - n_tx) * R + from];
+    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t i = i0; i < n_tx; i += (int64_t)gridDim.x * blockDim.x) x[i * R + r] = start[i];
+    if (i0 < EM_FINAL_BLOCKS) {
+        part_max[i0 * R + r] = 1e300;
+        part_flags[i0 * R + r] = 1u;
     }
 }
 
-// control block of a working set whose replicates `n_live` .. R-1 are unused: they count as stopped
-__global__ void em_batch_ctl_kernel(unsigned long long *ctl, int n_live)
+// out[t] = x[t][r]
+__global__ void __launch_bounds__(256)
+em_batch_take_kernel(const double *__restrict__ x, int64_t n_tx, int r, double *__restrict__ out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx;
+         i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i * R + r];
+}
+
+// fresh control block; the places in `idle` hold no replicate and count as stopped
+__global__ void em_batch_ctl_kernel(unsigned long long *ctl, unsigned int idle)
 {
     const int i = threadIdx.x;
-    if (i < 32) ctl[i] = (i >= BCTL_DONE + n_live && i < BCTL_DONE + R) ? 1ULL : 0ULL;
-}
-
-// out[r][t] = the result of replicate r (r < n_out): every replicate's last x has been carried to
-// the buffer the last executed step wrote (ctl == nullptr: the caller knows it, and passes it as x0)
-__global__ void __launch_bounds__(256)
-em_batch_result_kernel(const unsigned long long *__restrict__ ctl, const double *__restrict__ x0,
-                       const double *__restrict__ x1, int64_t n_tx, int n_out, double *__restrict__ out)
-{
-    const double *__restrict__ x = (ctl && (ctl[BCTL_LAST_STEP] & 1ULL)) ? x1 : x0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx * n_out;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / n_tx, t = i - r * n_tx;
-        out[i] = x[t * R + r];
-    }
+    if (i < 32) ctl[i] = (i >= BCTL_DONE && i < BCTL_DONE + R && ((idle >> (i - BCTL_DONE)) & 1u)) ? 1ULL : 0ULL;
 }
 
 inline unsigned grid_of(int64_t items, int per_block, int64_t cap = 256 * 8)
@@ -274,11 +262,11 @@ int em_batch_final_blocks(const EmBatchProblem &p)
     return (int)blocks;
 }
 
-void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream, bool judge_previous)
+void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream)
 {
     const int parity = (int)(step & 1);
     hipLaunchKernelGGL(em_inner_batch_kernel, dim3(grid_of(p.n_classes, 256)), dim3(256), 0, stream, p, parity,
-                       step > 0 && judge_previous ? em_batch_final_blocks(p) : 0, step);
+                       step > 0 ? em_batch_final_blocks(p) : 0, step);
     hipLaunchKernelGGL(em_rows_batch_kernel, dim3(grid_of(p.n_rows, 32)), dim3(256), 0, stream, p, parity);
     hipLaunchKernelGGL(em_finalize_batch_kernel, dim3((unsigned)em_batch_final_blocks(p)), dim3(256), 0, stream, p,
                        parity);
@@ -289,28 +277,21 @@ void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStre
     hipLaunchKernelGGL(em_decide_batch_kernel, dim3(1), dim3(256), 0, stream, p, em_batch_final_blocks(p), steps_done);
 }
 
-void launch_em_batch_start(const double *start, int64_t n_tx, double *x, hipStream_t stream)
+void launch_em_batch_place(const double *start, int64_t n_tx, int r, double *x, double *part_max,
+                           unsigned int *part_flags, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_batch_start_kernel, dim3(grid_of(n_tx * R, 256)), dim3(256), 0, stream, start, n_tx, x);
+    hipLaunchKernelGGL(em_batch_place_kernel, dim3(grid_of(std::max<int64_t>(n_tx, EM_FINAL_BLOCKS), 256)), dim3(256), 0,
+                       stream, start, n_tx, r, x, part_max, part_flags);
 }
 
-void launch_em_batch_move(const double *x_from, const double *count_from, int from, double *x_to,
-                          double *count_to, int to, int64_t n_tx, int64_t n_classes, hipStream_t stream)
+void launch_em_batch_take(const double *x, int64_t n_tx, int r, double *out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_batch_move_kernel, dim3(grid_of(n_tx + n_classes, 256)), dim3(256), 0, stream, x_from,
-                       count_from, from, x_to, count_to, to, n_tx, n_classes);
+    hipLaunchKernelGGL(em_batch_take_kernel, dim3(grid_of(n_tx, 256)), dim3(256), 0, stream, x, n_tx, r, out);
 }
 
-void launch_em_batch_ctl(unsigned long long *ctl, int n_live, hipStream_t stream)
+void launch_em_batch_ctl(unsigned long long *ctl, unsigned int idle, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_batch_ctl_kernel, dim3(1), dim3(64), 0, stream, ctl, n_live);
-}
-
-void launch_em_batch_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n_tx,
-                            int n_out, double *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(em_batch_result_kernel, dim3(grid_of(n_tx * n_out, 256)), dim3(256), 0, stream, ctl, x0, x1,
-                       n_tx, n_out, out);
+    hipLaunchKernelGGL(em_batch_ctl_kernel, dim3(1), dim3(64), 0, stream, ctl, idle);
 }
 
 }  // namespace skm

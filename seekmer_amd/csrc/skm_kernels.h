@@ -183,21 +183,17 @@ struct EmBatchProblem {
     double *part_max;             // [EM_FINAL_BLOCKS][EM_BATCH]
     unsigned int *part_flags;     // [EM_FINAL_BLOCKS][EM_BATCH]
 };
-// one step (inner, rows, finalize); step > 0 first judges the step before it -- unless the
-// partials of that step are not this working set's (replicates moved in from elsewhere)
-void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream, bool judge_previous = true);
+// one step (inner, rows, finalize); step > 0 first judges the step before it
+void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream);
 void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream);
-void launch_em_batch_start(const double *start, int64_t n_tx, double *x, hipStream_t stream);
-// replicate `from` of one working set (abundances read by the next step, counts) -> replicate
-// `to` of another
-void launch_em_batch_move(const double *x_from, const double *count_from, int from, double *x_to,
-                          double *count_to, int to, int64_t n_tx, int64_t n_classes, hipStream_t stream);
-// fresh control block; replicates n_live .. EM_BATCH-1 are unused and count as stopped
-void launch_em_batch_ctl(unsigned long long *ctl, int n_live, hipStream_t stream);
-// out[r][t], r < n_out: the replicates' results once everything queued has run
-void launch_em_batch_result(const unsigned long long *ctl, const double *x0, const double *x1, int64_t n_tx,
-                            int n_out, double *out, hipStream_t stream);
-
+// a new replicate in place r of the working set: x[t][r] = start[t] in the buffer the next step
+// reads, the previous step's partials for r set to "still changing"
+void launch_em_batch_place(const double *start, int64_t n_tx, int r, double *x, double *part_max,
+                           unsigned int *part_flags, hipStream_t stream);
+// out[t] = x[t][r]
+void launch_em_batch_take(const double *x, int64_t n_tx, int r, double *out, hipStream_t stream);
+// fresh control block; bit r of `idle`: place r holds no replicate and counts as stopped
+void launch_em_batch_ctl(unsigned long long *ctl, unsigned int idle, hipStream_t stream);
 // device-side construction of the two CSR views (skm_quant_setup.hip)
 struct QuantBuild {
     int64_t n_tx, n_classes, n_ids;

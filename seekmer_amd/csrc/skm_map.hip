@@ -326,6 +326,8 @@ __device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, TSet &se
 // all-pairs with fully unrolled code.  Longer slices, unsorted indices and the
 // counting build take the walks.
 constexpr int LIST_REGS = 16;
+constexpr uint32_t LIST_ALL = (1u << LIST_REGS) - 1u;
+static_assert(LIST_REGS % 2 == 0 && LIST_REGS <= 16, "keep_common pairs the right-hand entries");
 #define LIST_FAST(count) (!(count))
 constexpr int32_t NO_ENTRY = INT32_MIN;      // (would be transcript 2^31-1: cannot occur, n_targets < 2^30)
 constexpr int32_t NO_ENTRY_B = INT32_MIN + 1; // the same for the other side of a comparison: never equal to NO_ENTRY
@@ -397,7 +399,7 @@ __device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], c
             nearest = min(nearest, min((uint32_t)(a[i] ^ b[j]), (uint32_t)(a[i] ^ b[j + 1])));
         dropped |= min(nearest, 1u) << i;                 // 1 = a[i] is not in b
     }
-    return ~dropped & 0xffffu;
+    return ~dropped & LIST_ALL;
 }
 
 // KMerIndex._filter_on_contig, _common.pyx:185-235: two-pointer merge of the
@@ -418,7 +420,7 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
         int32_t a[LIST_REGS], t[LIST_REGS];
         bool twice_a, twice_t;
         load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, NO_ENTRY, a, twice_a);
-        load_list(ix, start, length, forward, 0xffffu, NO_ENTRY_B, t, twice_t);   // (order within the slice is immaterial)
+        load_list(ix, start, length, forward, LIST_ALL, NO_ENTRY_B, t, twice_t);   // (order within the slice is immaterial)
         const uint32_t keep = keep_common(a, t, twice_a | twice_t);
         if (keep == 0) return false;
         set.word0 = keep;

@@ -527,18 +527,18 @@ def test_bootstrap_draw_and_em(oracle, native_libs, monkeypatch):
     # (skm_em_batch.hip): the same draws, the same additions -- the same bits and step counts
     out8, _, iters8 = quant.bootstrap(n_boot, 1234, x0, l)
     out5, _, iters5 = quant.bootstrap(5, 1234, x0, l)             # (a short last group)
-    # replicates still running after their group's budget of steps go on together in a second
-    # working set: with the budget pinned low every replicate takes that way (groups of eight
-    # late ones, a short last one, results routed to their places) -- the same bits again
+    # the working set is looked at every few steps and stopped replicates are replaced by the next
+    # ones: whatever the interval (1: every step; 7, 40: several finish between two looks, or all
+    # of them) and however the replicates meet in the working set -- the same bits again
     tpm8, _, _ = quant.bootstrap(n_boot, 1234, x0, l, tpm=True)
-    for budget, n in (('1', n_boot), ('3', 21), ('7', n_boot)):
-        monkeypatch.setenv('SKM_BOOTSTRAP_BUDGET', budget)
+    for every, n in (('1', n_boot), ('7', 21), ('40', n_boot)):
+        monkeypatch.setenv('SKM_BOOTSTRAP_CHUNK', every)
         late, _, iters_late = quant.bootstrap(n, 1234, x0, l)
         np.testing.assert_array_equal(late, out[:n])
         np.testing.assert_array_equal(iters_late, iters[:n])
         late_tpm, _, _ = quant.bootstrap(n, 1234, x0, l, tpm=True)
         np.testing.assert_array_equal(late_tpm, tpm8[:n])
-    monkeypatch.delenv('SKM_BOOTSTRAP_BUDGET')
+    monkeypatch.delenv('SKM_BOOTSTRAP_CHUNK')
     quant.close()
     np.testing.assert_array_equal(counts, counts2)      # seeded: reproducible
     np.testing.assert_array_equal(out, out2)
@@ -587,9 +587,9 @@ def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs, monkeypatch):
     out8, _, iters8 = quant.bootstrap(n_boot, 20240, x0, eff)    # batched EM: bit for bit the same
     np.testing.assert_array_equal(out8, out)
     np.testing.assert_array_equal(iters8, iters)
-    monkeypatch.setenv('SKM_BOOTSTRAP_BUDGET', str(max(2, int(np.median(iters)) - 3)))
-    out_late, _, iters_late = quant.bootstrap(n_boot, 20240, x0, eff)   # about half of them finish late
-    monkeypatch.delenv('SKM_BOOTSTRAP_BUDGET')
+    monkeypatch.setenv('SKM_BOOTSTRAP_CHUNK', '11')                      # (another rhythm of looks and refills)
+    out_late, _, iters_late = quant.bootstrap(n_boot, 20240, x0, eff)
+    monkeypatch.delenv('SKM_BOOTSTRAP_CHUNK')
     np.testing.assert_array_equal(out_late, out)
     np.testing.assert_array_equal(iters_late, iters)
     # the handle holds the observed counts again afterwards
