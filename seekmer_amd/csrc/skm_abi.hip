@@ -1768,17 +1768,14 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     auto drop_sums = on_exit([&]() { sums.release(); });
     // infer.py:127-129 on `count` results in HBM (TPM scaling with numpy's sums), when TPM is asked for
     auto scale = [&](double *results, int64_t count) -> int {
-        if (!tpm) return SKM_OK;
+        if (!tpm || count <= 0) return SKM_OK;
         const int64_t n_blocks = (T + 8191) / 8192;
-        SKM_TRY(sums.ensure(n_blocks + 2));
-        double *const total = sums.p + n_blocks;
-        for (int64_t k = 0; k < count; ++k) {
-            double *const x = results + k * T;
-            launch_np_sum(x, T, 1000000.0, sums.p, total, q->stream);
-            launch_divide(x, T, total + 1, true, 0.001, q->stream);
-            launch_np_sum(x, T, 1000000.0, sums.p, total, q->stream);
-            launch_divide(x, T, total + 1, false, 0.0, q->stream);
-        }
+        SKM_TRY(sums.ensure((size_t)(count * (n_blocks + 2))));
+        double *const totals = sums.p + count * n_blocks;            // (sum, sum / 1e6) per replicate
+        launch_np_sum_many(results, T, count, T, 1000000.0, sums.p, totals, q->stream);
+        launch_divide_many(results, T, count, T, totals + 1, true, 0.001, q->stream);
+        launch_np_sum_many(results, T, count, T, 1000000.0, sums.p, totals, q->stream);
+        launch_divide_many(results, T, count, T, totals + 1, false, 0.0, q->stream);
         HIP_TRY(hipGetLastError());
         return SKM_OK;
     };
@@ -1824,7 +1821,7 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     p.x[0] = w.x0.p; p.x[1] = w.x1.p;
     p.n_total = (double)n_draws; p.rel_tol = rel_tol; p.x_floor = x_floor;
     p.ctl = w.ctl.p; p.part_max = w.part_max.p; p.part_flags = w.part_flags.p;
-    int64_t chunk = 6;                                           // steps between two looks at the working set
+    int64_t chunk = 4;                                           // steps between two looks at the working set
     if (const char *e = getenv("SKM_BOOTSTRAP_CHUNK")) chunk = std::max<int64_t>(1, atoll(e));   // (tests)
     unsigned long long *const verdict = q->pinned + 64;          // 32 words of the pinned block
     // the results of `slots` replicates at a time collect in boot_out and go home together
@@ -1872,6 +1869,28 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
             }
             HIP_TRY(hipGetLastError());
             if (!any) break;
+            // The tail: nothing left to put in, a few replicates still running.  A step of the
+            // working set costs the same however many places are live (~5 single-problem steps), so
+            // the last three or fewer go on one by one in the single-problem EM, from where they are.
+            int live = 0;
+            for (int r = 0; r < EM_BATCH; ++r) live += place[r] >= 0;
+            if (next >= w1 && live <= 3) {
+                for (int r = 0; r < EM_BATCH; ++r) {
+                    if (place[r] < 0) continue;
+                    launch_em_batch_take(p.x[k & 1], T, r, q->x0.p, q->stream);
+                    launch_em_batch_take(w.cls_count.p, C, r, q->cls_count.p, q->stream);
+                    HIP_TRY(hipGetLastError());
+                    q->n_total = (double)n_draws;
+                    int64_t more = 0;
+                    SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, &more, 8));
+                    HIP_TRY(hipMemcpyAsync(q->boot_out.p + (place[r] - w0) * T, (more & 1) ? q->x1.p : q->x0.p,
+                                           (size_t)T * 8, hipMemcpyDeviceToDevice, q->stream));
+                    if (iters_out) iters_out[place[r]] = k - since[r] + more;
+                    q->iters_total += (double)(k - since[r]);        // (em_run has counted its own)
+                    place[r] = -1;
+                }
+                break;
+            }
             launch_em_batch_ctl(w.ctl.p, idle, q->stream);
         }
         SKM_TRY(send_home(w0, w1 - w0));

@@ -635,8 +635,11 @@ __device__ __forceinline__ void np_sum_full_block(const double *__restrict__ a, 
 }
 
 __global__ void __launch_bounds__(512)
-np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ block_sums)
+np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict__ block_sums, int64_t stride)
 {
+    // (blockIdx.y: one of several vectors `stride` elements apart, its block sums after the others')
+    a += blockIdx.y * stride;
+    block_sums += blockIdx.y * (int64_t)gridDim.x;
     const int64_t first = blockIdx.x * (int64_t)8192;
     const int len = (int)min((int64_t)8192, n - first);
     if (len == 8192) {                      // (block-uniform)
@@ -670,10 +673,12 @@ np_sum_blocks_kernel(const double *__restrict__ a, int64_t n, double *__restrict
     }
 }
 
-// out[0] = the sum, out[1] = sum / divisor
+// out[0] = the sum, out[1] = sum / divisor (vector blockIdx.x of several: its own block sums and pair)
 __global__ void np_sum_final_kernel(const double *block_sums, int64_t n_blocks, double divisor, double *out)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    block_sums += blockIdx.x * n_blocks;
+    out += blockIdx.x * 2;
     double acc = 0.0;
     for (int64_t b = 0; b < n_blocks; ++b) acc += block_sums[b];
     out[0] = acc;
@@ -689,9 +694,11 @@ reciprocal_kernel(const double *__restrict__ l, int64_t n, double *__restrict__ 
 
 // x /= *s, then (TPM) x[x < floor] = 0
 __global__ void __launch_bounds__(256)
-divide_kernel(double *__restrict__ x, int64_t n, const double *__restrict__ s, bool threshold, double floor)
+divide_kernel(double *__restrict__ x, int64_t n, const double *__restrict__ s, bool threshold, double floor,
+              int64_t stride)
 {
-    const double d = *s;
+    x += blockIdx.y * stride;                 // (one of several vectors, each with its own divisor pair)
+    const double d = s[blockIdx.y * 2];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         double v = x[i] / d;
@@ -706,8 +713,24 @@ void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sum
     const int64_t n_blocks = (n + 8191) / 8192;
     if (n_blocks)
         hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks), dim3(512), 0, stream,
-                           a, n, block_sums);
+                           a, n, block_sums, (int64_t)0);
     hipLaunchKernelGGL(np_sum_final_kernel, dim3(1), dim3(1), 0, stream, block_sums, n_blocks, divisor, out);
+}
+
+// the same for `count` vectors of n elements, `stride` apart: block_sums holds count * ceil(n / 8192)
+// doubles, out[2 v] = sum of vector v, out[2 v + 1] = sum / divisor
+void launch_np_sum_many(const double *a, int64_t n, int64_t count, int64_t stride, double divisor,
+                        double *block_sums, double *out, hipStream_t stream)
+{
+    const int64_t n_blocks = (n + 8191) / 8192;
+    for (int64_t v0 = 0; v0 < count; v0 += 32768) {              // (gridDim.y is limited to 65535)
+        const unsigned here = (unsigned)std::min<int64_t>(32768, count - v0);
+        if (n_blocks)
+            hipLaunchKernelGGL(np_sum_blocks_kernel, dim3((unsigned)n_blocks, here), dim3(512), 0, stream,
+                               a + v0 * stride, n, block_sums + v0 * n_blocks, stride);
+        hipLaunchKernelGGL(np_sum_final_kernel, dim3(here), dim3(1), 0, stream, block_sums + v0 * n_blocks, n_blocks,
+                           divisor, out + 2 * v0);
+    }
 }
 
 void launch_reciprocal(const double *l, int64_t n, double *x, hipStream_t stream)
@@ -717,7 +740,18 @@ void launch_reciprocal(const double *l, int64_t n, double *x, hipStream_t stream
 
 void launch_divide(double *x, int64_t n, const double *s, bool threshold, double floor, hipStream_t stream)
 {
-    hipLaunchKernelGGL(divide_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, n, s, threshold, floor);
+    hipLaunchKernelGGL(divide_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, n, s, threshold, floor, (int64_t)0);
+}
+
+// vector v of `count` (n elements, `stride` apart) divided by s[2 v]
+void launch_divide_many(double *x, int64_t n, int64_t count, int64_t stride, const double *s, bool threshold,
+                        double floor, hipStream_t stream)
+{
+    for (int64_t v0 = 0; v0 < count; v0 += 32768) {
+        const unsigned here = (unsigned)std::min<int64_t>(32768, count - v0);
+        hipLaunchKernelGGL(divide_kernel, dim3(std::min<unsigned>(grid_for(n), 64u), here), dim3(256), 0, stream,
+                           x + v0 * stride, n, s + 2 * v0, threshold, floor, stride);
+    }
 }
 
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,

@@ -220,8 +220,15 @@ int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids);
 // numpy.sum(a) bit for bit -> out[0], out[1] = out[0] / divisor; block_sums: ceil(n/8192) doubles
 void launch_np_sum(const double *a, int64_t n, double divisor, double *block_sums, double *out,
                    hipStream_t stream);
+// the same for `count` vectors `stride` elements apart: block_sums: count * ceil(n / 8192) doubles,
+// out[2 v] = sum of vector v, out[2 v + 1] = sum / divisor
+void launch_np_sum_many(const double *a, int64_t n, int64_t count, int64_t stride, double divisor,
+                        double *block_sums, double *out, hipStream_t stream);
 void launch_reciprocal(const double *l, int64_t n, double *x, hipStream_t stream);
 void launch_divide(double *x, int64_t n, const double *s, bool threshold, double floor, hipStream_t stream);
+// vector v of `count` (n elements, `stride` apart) divided by s[2 v]
+void launch_divide_many(double *x, int64_t n, int64_t count, int64_t stride, const double *s, bool threshold,
+                        double floor, hipStream_t stream);
 void launch_effective_lengths(const unsigned long long *fld, const double *lengths, int64_t n_tx,
                               double *out, hipStream_t stream);
 // multinomial(n_draws, counts / n_draws) over the classes whose inclusive cumulative counts are
