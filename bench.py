@@ -182,7 +182,8 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
         log('wrote %.1f GB of FASTQ text to %s in %.1fs' % (need / 1e9, folder, time.perf_counter() - t0))
         threads = max(1, min(args.parse_threads, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity')
                                                   else os.cpu_count() or 1)))
-        batch_units = (n_units + pieces - 1) // pieces
+        fastq_pieces = max(1, args.e2e_fastq_batches)
+        batch_units = (n_units + fastq_pieces - 1) // fastq_pieces
 
         def parse_only():
             t0 = time.perf_counter()
@@ -212,7 +213,7 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
                    'passes and its page-locked slabs pooled, each pass counts the newlines and parses anew) -> '
                    'NativeReadFeeder(threads=%d, pinned) in %d batches -> skm_mapper_map_batch[_uniform]_async -> '
                    'skm_quant_infer; best of %d passes'
-                   % (2 * read_len + 19, threads, pieces, passes)}
+                   % (2 * read_len + 19, threads, fastq_pieces, passes)}
     finally:
         shutil.rmtree(folder, ignore_errors=True)
     return out
@@ -232,7 +233,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=1_000_000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
-    ap.add_argument('--e2e-batches', type=int, default=10)
+    ap.add_argument('--e2e-batches', type=int, default=10, help='pieces of the host-array leg')
+    ap.add_argument('--e2e-fastq-batches', type=int, default=40,
+                    help='batches of the FASTQ leg (each is parsed by one thread: smaller batches reach the GPU sooner)')
     ap.add_argument('--parse-threads', type=int, default=12)
     ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
     args = ap.parse_args()
