@@ -301,7 +301,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 // draw takes its own 64-bit hash and a 64 x 64 multiply-high; 32-bit multiplies issue at a
 // quarter of the rate), so: one 64-bit hash serves TWO draws, each an exactly uniform integer
 // below the range from 32 bits by multiply-high with rejection (Lemire; rejected with
-// probability range / 2^32, then redrawn from a stream of its own), and the interval holding r
+// probability range / 2^32, then redrawn from a stream keyed by the draw's number), and the interval holding r
 // is found from a guide table over power-of-two buckets of r (one LDS read, then 1-2 steps
 // forward) instead of a 12-step binary search.
 constexpr int MN_TILES = 4096;
@@ -309,24 +309,23 @@ constexpr int MN_GUIDE_BITS = 12;
 
 struct MnStream {
     uint64_t base, spare;      // counter-mode keys of the paired draws and of the redraws
-    uint64_t redraws;
     __device__ __forceinline__ MnStream(uint64_t seed, uint64_t stream_id, uint64_t part)
     {
         base = mix64(seed ^ (stream_id * 0x9E3779B97F4A7C15ULL) ^ (part * 0xC2B2AE3D27D4EB4FULL));
         spare = mix64(base ^ 0xA0761D6478BD642FULL);
-        redraws = 0;
     }
     // the two 32-bit words of draw pair number `pair`
     __device__ __forceinline__ uint64_t words(uint64_t pair) const { return mix64(base + pair * 0xD1342543DE82EF95ULL); }
 };
 // exactly uniform in [0, range), range >= 1, from 32 random bits; `reject_below` = 2^32 mod range.
-// A rejected word is replaced from the lane's own redraw stream (pair number and lane identify it).
-__device__ __forceinline__ uint32_t mn_bounded(uint32_t word, uint32_t range, uint32_t reject_below, MnStream &rng,
-                                               uint64_t pair)
+// A rejected word is replaced from a stream keyed by (pair, which of its two draws, attempt): the
+// result depends on the draw's number alone, not on which lane of which launch geometry makes it.
+__device__ __forceinline__ uint32_t mn_bounded(uint32_t word, uint32_t range, uint32_t reject_below,
+                                               const MnStream &rng, uint64_t pair, uint32_t which)
 {
     uint64_t m = (uint64_t)word * range;
-    while ((uint32_t)m < reject_below) {
-        const uint64_t again = mix64(rng.spare + pair * 0xD1342543DE82EF95ULL + (++rng.redraws) * 0x9FB21C651E98DF25ULL);
+    for (uint64_t attempt = 1; (uint32_t)m < reject_below; ++attempt) {
+        const uint64_t again = mix64(rng.spare + pair * 0xD1342543DE82EF95ULL + (2 * attempt + which) * 0x9FB21C651E98DF25ULL);
         m = (uint64_t)(uint32_t)(again >> 32) * range;
     }
     return (uint32_t)(m >> 32);
@@ -384,10 +383,10 @@ multinomial_tiles_kernel(const unsigned long long *__restrict__ cum, int64_t n_c
     const int64_t first = n_pairs * blockIdx.x / gridDim.x, last = n_pairs * (blockIdx.x + 1) / gridDim.x;
     for (int64_t p = first + threadIdx.x; p < last; p += blockDim.x) {
         const uint64_t w = rng.words((uint64_t)p);
-        const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), total, reject_below, rng, (uint64_t)p);
+        const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), total, reject_below, rng, (uint64_t)p, 0u);
         atomicAdd(&count[mn_find(tile_cum, guide, shift, r0)], 1u);
         if (2 * p + 1 < n_draws) {
-            const uint32_t r1 = mn_bounded((uint32_t)w, total, reject_below, rng, (uint64_t)p);
+            const uint32_t r1 = mn_bounded((uint32_t)w, total, reject_below, rng, (uint64_t)p, 1u);
             atomicAdd(&count[mn_find(tile_cum, guide, shift, r1)], 1u);
         }
     }
@@ -397,6 +396,9 @@ multinomial_tiles_kernel(const unsigned long long *__restrict__ cum, int64_t n_c
 }
 
 // counts[(first_class + i) * stride] = draws of class first_class + i, as f8 (the EM's class counts)
+// (the guide keeps its 4096 buckets for a tile of a few hundred classes too: with 512 the scans
+// through the light classes of a bucket made this kernel 128 us instead of 72; and 256-lane
+// workgroups, four per CU by their LDS, ran 353 us)
 __global__ void __launch_bounds__(1024)
 multinomial_classes_kernel(const unsigned long long *__restrict__ cum, int64_t n_classes, int tile,
                            const unsigned int *__restrict__ tile_total, uint64_t seed, uint64_t stream_id,
@@ -424,10 +426,10 @@ multinomial_classes_kernel(const unsigned long long *__restrict__ cum, int64_t n
         const unsigned int n_pairs = (draws + 1) >> 1;
         for (unsigned int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
             const uint64_t w = rng.words(p);
-            const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), mass, reject_below, rng, p);
+            const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), mass, reject_below, rng, p, 0u);
             atomicAdd(&count[mn_find(local_cum, guide, shift, r0)], 1u);
             if (2 * p + 1 < draws) {
-                const uint32_t r1 = mn_bounded((uint32_t)w, mass, reject_below, rng, p);
+                const uint32_t r1 = mn_bounded((uint32_t)w, mass, reject_below, rng, p, 1u);
                 atomicAdd(&count[mn_find(local_cum, guide, shift, r1)], 1u);
             }
         }
