@@ -437,6 +437,45 @@ def test_class_views_when_first_seen_values_are_shared(oracle, native_libs):
     np.testing.assert_allclose(x_own, x_dev, rtol=1e-6 if it_host != it_dev else 1e-9, atol=1e-300)
 
 
+def test_quantification_through_a_one_rank_communicator(oracle, native_libs):
+    """The N > 1 data path with N = 1: an RCCL communicator of one rank is created as the ranks of
+    a sharded run create theirs, skm_quant_infer all-reduces the histogram + aligned total and the
+    per-step numerators through it, a bootstrap handle with the communicator attached takes the
+    one-by-one path (its collectives must stay matched).  A sum over one rank is the identity:
+    the same bits as without the communicator, the same step count."""
+    import ctypes
+    from seekmer_amd import synth, index_builder, infer, parallel, _native
+    ids, pool, tx_offsets = synth.transcriptome(9, 50)
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    n_units = 30000
+    bases, offsets = synth.reads(9, pool, tx_offsets, 0, n_units, 100, True)
+    result, _ = _run_gpu(index, bases, offsets, n_units, True)
+    tpm, iters, eff = infer.quantify_resident(result, return_iters=True, return_effective_lengths=True)
+    hip = _native.hip()
+    raw = ctypes.create_string_buffer(128)
+    _native.check(hip.skm_comm_unique_id(raw))
+    comm = parallel.create_comm(0, raw.raw, 0, 1)
+    try:
+        n = ctypes.c_int(0)
+        _native.check(hip.skm_comm_count(comm, ctypes.byref(n)))
+        assert n.value == 1
+        tpm_c, iters_c, eff_c = infer.quantify_resident(result, comm=comm, return_iters=True,
+                                                        return_effective_lengths=True)
+        assert iters_c == iters
+        np.testing.assert_array_equal(eff_c, eff)
+        np.testing.assert_array_equal(tpm_c, tpm)
+        x0 = tpm / tpm.sum()
+        quant = infer._QuantHandle.from_map_result(result, len(ids))
+        plain, _, steps = quant.bootstrap(11, 77, x0, eff)            # (the working set of eight)
+        _native.check(hip.skm_quant_set_comm(quant.handle, comm))
+        through, _, steps_c = quant.bootstrap(11, 77, x0, eff)        # (one by one, all-reduced)
+        quant.close()
+        np.testing.assert_array_equal(steps_c, steps)
+        np.testing.assert_array_equal(through, plain)
+    finally:
+        parallel.destroy_comm(comm)
+
+
 def test_em_skewed_and_degenerate_tables(oracle, native_libs):
     """A transcript in thousands of classes (several 512-entry rows), duplicate
     ids inside a tuple, transcripts in no class, zero counts (bootstrap), and
