@@ -122,33 +122,89 @@ def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units, paired, 
 
 
 def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, passes=3):
-    """configs[1] once more from outside the GPU (N = 1 only): (a) the batch in page-locked host
-    arrays, handed over in `--e2e-batches` pieces through skm_mapper_map_batch_async (copy of
-    piece i+1 under the kernels of piece i), then the resident quantification; (b) the same reads
-    as FASTQ text on the host's RAM disk, parsed by the native reader's parallel engine into
-    page-locked slabs and handed over the same way.  Best of `passes`."""
+    """configs[1] once more from outside the GPU (N = 1 only), none of it `value`:
+    (a) `pcie_inclusive`: the reads as the mapper takes them from a host -- 2-bit code words, 32 bytes
+        per 100-base read -- in page-locked host arrays, pushed in `--e2e-batches` pieces per stream
+        (skm_mapper_push_packed: the copy of a piece runs under the kernels of the ones before), then
+        the resident quantification; `ascii` beside it: the same reads as ASCII bases (100 bytes per
+        read, packed on the device) through skm_mapper_map_batch_uniform_async;
+    (b) `fastq_inclusive`: the same reads as FASTQ text on the host's RAM disk, parsed to code words
+        in ONE pass by the native reader's workers and drained into the mapper natively
+        (skm_mapper_map_packed_source over skm_fastq_packed_next), then the quantification;
+        `two_pass_ascii` beside it: last round's path (newline index, ASCII slabs).
+    Best of `passes`; the first pass (cold file mapping, cold pools) is reported too."""
     from seekmer_amd import common, infer, mapper, synth
     out = {}
     read_len, pieces = args.read_len, max(1, args.e2e_batches)
+    _native.check(hip.skm_pinned_set_device(device))
     result = mapper.MapResult(index, device=device)
     rm = mapper.ReadMapper(index, result)
-    # ---- (a) host arrays -> TPM
-    n_bytes = bases.size
-    p_bases = hip.skm_pinned_alloc(n_bytes)
-    p_offsets = hip.skm_pinned_alloc(offsets.size * 8)
-    if not p_bases or not p_offsets:
-        raise RuntimeError('cannot page-lock %d bytes of host memory' % (n_bytes + offsets.size * 8))
-    h_bases = np.ctypeslib.as_array(ctypes.cast(p_bases, ctypes.POINTER(ctypes.c_uint8)), (n_bytes,))
-    h_offsets = np.ctypeslib.as_array(ctypes.cast(p_offsets, _native.c_i64p), (offsets.size,))
-    h_bases[:] = bases
-    h_offsets[:] = offsets
-    cut = [n_units * k // pieces for k in range(pieces + 1)]
+    host = _native.host()
 
-    def from_host():
+    def pinned_copy(array):
+        raw = hip.skm_pinned_alloc(array.nbytes)
+        if not raw:
+            raise RuntimeError('cannot page-lock %d bytes of host memory' % array.nbytes)
+        view = np.ctypeslib.as_array(ctypes.cast(raw, ctypes.POINTER(ctypes.c_uint8)), (array.nbytes,))
+        view[:] = array.reshape(-1).view(np.uint8)
+        return raw, view.view(array.dtype).reshape(array.shape)
+
+    # ---- (a) host arrays -> TPM
+    cut = [n_units * k // pieces for k in range(pieces + 1)]
+    t0 = time.perf_counter()
+    lengths = np.full(n_units, read_len, dtype=np.uint32)
+    streams, held = [], []
+    flat = bases[:2 * n_units * read_len].reshape(n_units, 2, read_len)
+    for s in range(2):
+        mate = np.ascontiguousarray(flat[:, s, :]).reshape(-1)
+        piece = common.PackedReads.from_ascii(np.concatenate([mate, np.zeros(1, np.uint8)]),
+                                              np.arange(n_units + 1, dtype=np.int64) * read_len, stream=s, paired=True)
+        assert piece.raw.n_exceptions == 0
+        raw, codes = pinned_copy(np.array(piece.codes))
+        held.append(raw)
+        streams.append(codes)
+    log('packed the reads for the host-array leg in %.1fs' % (time.perf_counter() - t0))
+    packed_bytes = sum(c.nbytes for c in streams)
+
+    def from_host_packed():
         result.reset()
         t0 = time.perf_counter()
         for k in range(pieces):
-            sub = common.ReadBatch(cut[k + 1] - cut[k], h_bases, h_offsets[2 * cut[k]:2 * cut[k + 1] + 1], True,
+            for s in range(2):
+                rm.push_packed(common.PackedReads.from_arrays(s, cut[k], streams[s][cut[k]:cut[k + 1]],
+                                                              lengths[cut[k]:cut[k + 1]], paired=True))
+        result.sync()
+        t_map = time.perf_counter() - t0
+        infer.quantify_resident(result)
+        return t_map, time.perf_counter() - t0
+
+    runs = [from_host_packed() for _ in range(passes + 1)]
+    best = min(runs, key=lambda t: t[1])
+    classes_host = result.sizes()
+    out['pcie_inclusive'] = {
+        'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
+        'first_pass': n_units / runs[0][1],
+        'host_bytes': int(packed_bytes), 'bytes_per_pair': packed_bytes / n_units,
+        'GBps_over_pcie': packed_bytes / best[0] / 1e9,
+        'how': '%d pairs as 2-bit code words (%d bytes per pair) in page-locked host arrays, %d pieces per stream '
+               'through skm_mapper_push_packed, then skm_quant_infer; best of %d passes'
+               % (n_units, packed_bytes // n_units, pieces, passes)}
+    for raw in held:
+        hip.skm_pinned_free(raw)
+    del streams
+    # the same from ASCII bases (what round 2 measured)
+    n_bytes = bases.size
+    p_bases = hip.skm_pinned_alloc(n_bytes)
+    if not p_bases:
+        raise RuntimeError('cannot page-lock %d bytes of host memory' % n_bytes)
+    h_bases = np.ctypeslib.as_array(ctypes.cast(p_bases, ctypes.POINTER(ctypes.c_uint8)), (n_bytes,))
+    h_bases[:] = bases
+
+    def from_host_ascii():
+        result.reset()
+        t0 = time.perf_counter()
+        for k in range(pieces):
+            sub = common.ReadBatch(cut[k + 1] - cut[k], h_bases, offsets[2 * cut[k]:2 * cut[k + 1] + 1], True,
                                    first_unit=cut[k], uniform_len=read_len)
             rm.map_batch_async(sub)
         result.sync()
@@ -156,16 +212,11 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
         infer.quantify_resident(result)
         return t_map, time.perf_counter() - t0
 
-    best = min((from_host() for _ in range(passes + 1)), key=lambda t: t[1])
-    out['pcie_inclusive'] = {
-        'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
-        'host_bytes': int(n_bytes), 'GBps_over_pcie': n_bytes / best[0] / 1e9,
-        'how': '%d pairs in page-locked host arrays (skm_pinned_alloc), %d batches of equal-length reads through '
-               'skm_mapper_map_batch_uniform_async (no offsets over the link), then skm_quant_infer; best of %d passes'
-               % (n_units, pieces, passes)}
-    classes_host = result.sizes()
+    best = min((from_host_ascii() for _ in range(passes)), key=lambda t: t[1])
+    assert result.sizes() == classes_host
+    out['pcie_inclusive']['ascii'] = {'value': n_units / best[1], 'through_mapping': n_units / best[0],
+                                      'host_bytes': int(n_bytes), 'GBps_over_pcie': n_bytes / best[0] / 1e9}
     hip.skm_pinned_free(p_bases)
-    hip.skm_pinned_free(p_offsets)
     # ---- (b) FASTQ text -> TPM
     ram = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
     need = 2 * n_units * (2 * read_len + 19)
@@ -180,41 +231,65 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
         t0 = time.perf_counter()
         synth.write_fastq(bases, n_units, read_len, True, p1, p2)
         log('wrote %.1f GB of FASTQ text to %s in %.1fs' % (need / 1e9, folder, time.perf_counter() - t0))
-        threads = max(1, min(args.parse_threads, (len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity')
-                                                  else os.cpu_count() or 1)))
-        fastq_pieces = max(1, args.e2e_fastq_batches)
-        batch_units = (n_units + fastq_pieces - 1) // fastq_pieces
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        threads = max(1, min(args.parse_threads, cores))
+        chunk = args.e2e_chunk_mb << 20
+
+        def feeder():
+            return common.PackedReadFeeder([p1, p2], True, threads=threads, chunk_bytes=chunk, pinned=True)
 
         def parse_only():
             t0 = time.perf_counter()
-            count = 0
-            for batch in common.NativeReadFeeder([p1, p2], True, batch_units=batch_units, threads=threads, pinned=True):
-                count += batch.count
-            assert count == n_units
+            count = sum(piece.n_reads for piece in feeder())
+            assert count == 2 * n_units
             return time.perf_counter() - t0
 
         def from_fastq():
             result.reset()
             t0 = time.perf_counter()
-            feeder = common.NativeReadFeeder([p1, p2], True, batch_units=batch_units, threads=threads, pinned=True)
-            rm(feeder)                       # the reference's mapping loop: every batch handed over, then sync
+            source = feeder()
+            rm(source)                       # the reference's mapping loop: every piece handed over, then sync
             t_map = time.perf_counter() - t0
             infer.quantify_resident(result)
-            return t_map, time.perf_counter() - t0, feeder.parallel
+            return t_map, time.perf_counter() - t0, source.stats
 
+        cold = from_fastq()                  # first pass: the files are mapped and the pools filled here
+        assert result.sizes() == classes_host                # same classes as from the host arrays
+        _native.check_host(host.skm_fastq_cache_bytes(2 * need), 'skm_fastq_cache_bytes')   # later passes re-use the mappings
+        from_fastq()
         t_parse = min(parse_only() for _ in range(2))
-        best = min((from_fastq() for _ in range(passes + 1)), key=lambda t: t[1])
-        assert result.sizes() == classes_host           # same classes as from the host arrays
+        runs = [from_fastq() for _ in range(passes)]
+        best = min(runs, key=lambda t: t[1])
+        assert result.sizes() == classes_host
         out['fastq_inclusive'] = {
             'value': n_units / best[1], 'unit': 'pairs/s', 'through_mapping': n_units / best[0],
+            'first_pass': n_units / cold[1],
             'parse_only': n_units / t_parse, 'text_GBps': need / best[0] / 1e9, 'parse_threads': threads,
-            'parallel_engine': bool(best[2]),
-            'how': 'two FASTQ files (%d bytes per record, RAM disk; the reader keeps a file mapped between '
-                   'passes and its page-locked slabs pooled, each pass counts the newlines and parses anew) -> '
-                   'NativeReadFeeder(threads=%d, pinned) in %d batches -> skm_mapper_map_batch[_uniform]_async -> '
-                   'skm_quant_infer; best of %d passes'
-                   % (2 * read_len + 19, threads, fastq_pieces, passes)}
+            'chunk_mb': args.e2e_chunk_mb, 'reader': best[2],
+            'how': 'two FASTQ files (%d bytes per record, RAM disk) -> PackedReadFeeder(threads=%d, pinned, one pass '
+                   'over the text, 2-bit code words) -> skm_mapper_map_packed_source -> skm_quant_infer; best of %d '
+                   'passes with the files\' mappings and the page-locked pieces kept between passes, `first_pass` '
+                   'without either' % (2 * read_len + 19, threads, passes)}
+
+        # last round's path beside it: newline index + ASCII slabs
+        fastq_pieces = max(1, args.e2e_fastq_batches)
+        batch_units = (n_units + fastq_pieces - 1) // fastq_pieces
+
+        def from_fastq_ascii():
+            result.reset()
+            t0 = time.perf_counter()
+            source = common.NativeReadFeeder([p1, p2], True, batch_units=batch_units, threads=min(threads, 12), pinned=True)
+            rm(source)
+            t_map = time.perf_counter() - t0
+            infer.quantify_resident(result)
+            return t_map, time.perf_counter() - t0
+
+        best = min((from_fastq_ascii() for _ in range(passes)), key=lambda t: t[1])
+        assert result.sizes() == classes_host
+        out['fastq_inclusive']['two_pass_ascii'] = {'value': n_units / best[1], 'through_mapping': n_units / best[0],
+                                                    'batches': fastq_pieces}
     finally:
+        host.skm_fastq_cache_bytes(0)
         shutil.rmtree(folder, ignore_errors=True)
     return out
 
@@ -235,8 +310,9 @@ def main():
     ap.add_argument('--no-e2e', action='store_true')
     ap.add_argument('--e2e-batches', type=int, default=10, help='pieces of the host-array leg')
     ap.add_argument('--e2e-fastq-batches', type=int, default=40,
-                    help='batches of the FASTQ leg (each is parsed by one thread: smaller batches reach the GPU sooner)')
-    ap.add_argument('--parse-threads', type=int, default=12)
+                    help='batches of the two-pass ASCII comparison leg')
+    ap.add_argument('--parse-threads', type=int, default=14)
+    ap.add_argument('--e2e-chunk-mb', type=int, default=16, help='text range one parser thread takes at a time')
     ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
     args = ap.parse_args()
     shape = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100)}

@@ -60,6 +60,10 @@ int skm_device_synchronize(int device);
  * signatures: skm_fastq_set_allocator takes this pair so that FASTQ slabs are page-locked. */
 void *skm_pinned_alloc(size_t bytes);
 void skm_pinned_free(void *ptr);
+/* The GPU whose context page-locks the memory (default 0; one process per GPU sets its own before
+ * the FASTQ reader's threads allocate).  The memory is portable: any device of the process may
+ * copy from it. */
+int skm_pinned_set_device(int device);
 /* Diagnostic: rate of random 16-byte gathers over a table of `table_bytes`
  * (power of two); chain=0 independent (throughput), chain=1 dependent
  * (latency under load).  The ceiling the index probes are priced against. */
@@ -130,6 +134,44 @@ int skm_mapper_map_batch_async(skm_mapper *mapper, const char *bases,
 int skm_mapper_map_batch_uniform_async(skm_mapper *mapper, const char *bases, int32_t read_len,
                                        int64_t n_units, int paired, int64_t first_unit);
 int skm_mapper_sync(skm_mapper *mapper);
+/* Reads packed on the host.
+ * The mapper works on 2-bit codes and one "is an upper-case ACGT" bit per base
+ * (seekmer/_kmer.pxd:253-273, seekmer/_mapper.pyx:500-501); in FASTQ text nearly every read has all
+ * of those bits set.  A piece carries its reads as code words only (32 bases per u64 word, first
+ * base in the top two bits, zero beyond the read's end: 32 bytes for a 100-base read) plus an
+ * exception entry -- the bit plane -- for each read that holds any other character. */
+typedef struct skm_packed_reads {
+    int32_t stream;                  /* 0 = single-end reads / mate 1 files, 1 = mate 2 files */
+    int32_t code_words;              /* u64 words per read in `codes` */
+    int64_t first_read;              /* place of reads[0] in its stream = the unit it belongs to */
+    int64_t n_reads;                 /* 0 = end of the sample */
+    int64_t read_stride;             /* u64 words from one read's codes to the next (>= code_words) */
+    int64_t uniform_len;             /* >= 0: every read is this long and `lengths` may be NULL */
+    const uint64_t *codes;           /* read r = codes[r * read_stride .. + code_words) */
+    const uint32_t *lengths;         /* [n_reads] */
+    int64_t n_exceptions;
+    const uint32_t *exception_reads; /* [n_exceptions] indices into this piece, ascending */
+    const uint32_t *exception_masks; /* [n_exceptions][code_words]: bit 31 - i of word w set = base
+                                        32 w + i is an upper-case A, C, G or T */
+    const char *names;               /* stream 0 only, and only when asked for: names back to back */
+    const int64_t *name_offsets;     /* [n_reads + 1] */
+} skm_packed_reads;
+/* ReadMapper.__call__ (seekmer/_mapper.pyx:73-101) for reads that arrive packed.  A piece is copied
+ * to HBM by the calling thread (the call returns when its arrays are free again) and joins its
+ * stream; the mapper's worker maps, in the background and in launches as large as what has arrived,
+ * every run of units that its streams cover (single-ended: stream 0 alone; paired: unit u = read u
+ * of stream 0 + read u of stream 1).  A piece whose first_read lies below the end of what its stream
+ * holds replaces the reads from there on.  skm_mapper_sync -- and every call that reads the table
+ * -- first maps what is still waiting; reads left without a mate at that point are dropped
+ * (zip(file1, file2): seekmer/common.py:180-197).  Class order does not depend on how the
+ * pieces were cut or when they arrived: first-seen values are unit numbers. */
+int skm_mapper_push_packed(skm_mapper *mapper, const skm_packed_reads *piece, int paired);
+/* Drain a source of pieces (skm_fastq_packed_next with its reader as context) into the mapper
+ * without leaving native code: next() until a piece with n_reads == 0, every piece pushed.
+ * *n_pieces (optional) = pieces pushed. */
+typedef int (*skm_packed_source)(void *context, skm_packed_reads *piece);
+int skm_mapper_map_packed_source(skm_mapper *mapper, skm_packed_source next, void *context,
+                                 int paired, int64_t *n_pieces);
 /* Same with the batch already resident in HBM (device pointers; max_read_len
  * must bound every read length). */
 int skm_mapper_map_batch_device(skm_mapper *mapper, const void *d_bases,
@@ -295,6 +337,51 @@ typedef struct skm_fastq_slab skm_fastq_slab;
 int skm_fastq_detach(skm_fastq *reader, skm_fastq_slab **slab);
 int skm_fastq_recycle(skm_fastq *reader, skm_fastq_slab *slab);
 int skm_fastq_close(skm_fastq *reader);
+
+/* Bytes of file mappings nobody has open that the readers may keep for the next reader of the same
+ * file (default 0: a mapping goes when its last reader closes; a caller that reads the same files
+ * again and again -- a benchmark's passes -- saves the page-table set-up of the later passes). */
+int skm_fastq_cache_bytes(int64_t bytes);
+
+/* ---- FASTQ text -> 2-bit reads on the host (skm_packed_reads, above) ------------------------- */
+/* feed_single_ended_reads / feed_pair_ended_reads (seekmer/common.py:126-197) for plain (not
+ * compressed) files, straight to packed pieces in ONE pass over the text: the files are cut into
+ * `chunk_bytes` ranges that n_threads workers parse side by side, each from the first place in its
+ * range that looks like a record start; the reader hands the pieces out in file order and checks,
+ * piece by piece, that the walk before ended exactly where this one started -- the reference's
+ * rule is purely line-number based (`i & 3`), and only that chain proves a guessed start to be a
+ * line with i & 3 == 0.  A piece whose guess fails is parsed again from the proven place (one
+ * thread), so the reads are the reference's for any text.  Paired input is two streams, mate 1
+ * files and mate 2 files, each numbered by unit; a pair of files counts min(records) units
+ * (zip(file1, file2)), and a piece whose first_read lies below what its stream already delivered
+ * replaces the reads from there on.  A trailing name line without a bases line is dropped.
+ * n_threads = 0 parses inside skm_fastq_packed_next.  SKM_ERR_IO: not regular files (pipes from
+ * decompressors go through skm_fastq_open). */
+typedef struct skm_fastq_packed skm_fastq_packed;
+int skm_fastq_packed_open(const char *const *paths, int n_paths, int paired, int n_threads,
+                          int64_t chunk_bytes, int want_names, skm_fastq_packed **out);
+/* where the arrays that cross PCIe live (before the first _next; see skm_fastq_set_allocator) */
+int skm_fastq_packed_set_allocator(skm_fastq_packed *reader, void *(*alloc)(size_t),
+                                   void (*release)(void *));
+/* next piece; piece->n_reads == 0 at the end.  The arrays stay valid until the next call.  The
+ * signature is skm_packed_source (below) with the reader as context. */
+int skm_fastq_packed_next(void *reader, skm_packed_reads *piece);
+/* stats[0]=pieces accepted as guessed [1]=pieces parsed again [2]=reads [3]=exceptions
+ * [4]=parser variant in use (0 single characters, 1 16-byte blocks, 2 32-byte blocks)
+ * [5]=units of the sample so far (paired: min over the two streams, per pair of files) */
+int skm_fastq_packed_stats(const skm_fastq_packed *reader, int64_t stats[8]);
+int skm_fastq_packed_close(skm_fastq_packed *reader);
+/* The same packing for reads that are already in memory (bases back to back + offsets, the layout
+ * of skm_mapper_map_batch): codes[n_reads][code_words], lengths[n_reads]; exception arrays hold up
+ * to cap_exceptions entries, *n_exceptions = how many there are (SKM_ERR_STATE when more than the
+ * capacity, SKM_ERR_ARG when a read is longer than 32 * code_words).  variant: -1 best available,
+ * or 0 / 1 / 2 as in skm_fastq_packed_stats (SKM_ERR_STATE when this CPU lacks it). */
+int skm_pack_reads(const char *bases, const int64_t *offsets, int64_t n_reads, int32_t code_words,
+                   uint64_t *codes, uint32_t *lengths, uint32_t *exception_reads,
+                   uint32_t *exception_masks, int64_t cap_exceptions, int64_t *n_exceptions,
+                   int variant);
+/* force the parser variant of readers opened from now on (-1: best available); tests */
+int skm_pack_set_variant(int variant);
 
 /* Seeded synthetic data; integer arithmetic only. */
 int skm_synth_transcriptome(uint64_t seed, int64_t n_genes, int64_t *n_tx,

@@ -26,6 +26,18 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_f64p = ctypes.POINTER(ctypes.c_double)
 c_i64 = ctypes.c_int64
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class PackedReads(ctypes.Structure):
+    """skm_packed_reads (include/seekmer_hip.h)"""
+    _fields_ = [('stream', ctypes.c_int32), ('code_words', ctypes.c_int32), ('first_read', ctypes.c_int64),
+                ('n_reads', ctypes.c_int64), ('read_stride', ctypes.c_int64), ('uniform_len', ctypes.c_int64),
+                ('codes', ctypes.c_void_p), ('lengths', ctypes.c_void_p), ('n_exceptions', ctypes.c_int64),
+                ('exception_reads', ctypes.c_void_p), ('exception_masks', ctypes.c_void_p),
+                ('names', ctypes.c_void_p), ('name_offsets', ctypes.c_void_p)]
+
 
 # every symbol include/seekmer_hip.h declares, by library
 HIP_SYMBOLS = {
@@ -40,6 +52,7 @@ HIP_SYMBOLS = {
                                                  ctypes.c_int, c_f64p]),
     'skm_pinned_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
     'skm_pinned_free': (None, [ctypes.c_void_p]),
+    'skm_pinned_set_device': (ctypes.c_int, [ctypes.c_int]),
     'skm_index_create': (ctypes.c_int, [ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_void_p, c_i64, ctypes.c_void_p, c_i64,
                                         ctypes.c_int, c_void_pp]),
@@ -55,6 +68,9 @@ HIP_SYMBOLS = {
     'skm_mapper_map_batch_uniform_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, c_i64,
                                                           ctypes.c_int, c_i64]),
     'skm_mapper_sync': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_mapper_push_packed': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PackedReads), ctypes.c_int]),
+    'skm_mapper_map_packed_source': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                    c_i64p]),
     'skm_mapper_map_batch_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, c_i64, ctypes.c_int,
                                                    ctypes.c_int32]),
@@ -113,6 +129,17 @@ HOST_SYMBOLS = {
     'skm_fastq_detach': (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
     'skm_fastq_recycle': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_close': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_fastq_cache_bytes': (ctypes.c_int, [c_i64]),
+    'skm_fastq_packed_open': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, c_i64, ctypes.c_int, c_void_pp]),
+    'skm_fastq_packed_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'skm_fastq_packed_next': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PackedReads)]),
+    'skm_fastq_packed_stats': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
+    'skm_fastq_packed_close': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_pack_reads': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_i64, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64p,
+                                      ctypes.c_int]),
+    'skm_pack_set_variant': (ctypes.c_int, [ctypes.c_int]),
     'skm_synth_transcriptome': (ctypes.c_int, [ctypes.c_uint64, c_i64, c_i64p, c_void_pp,
                                                c_void_pp]),
     'skm_synth_free': (ctypes.c_int, [ctypes.c_void_p]),

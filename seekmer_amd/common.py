@@ -24,7 +24,7 @@ from . import _native
 
 __all__ = ('INVALID_INDEX', 'BUFFER_SIZE', 'decompress_and_open', 'read_fasta',
            'iterate_by_group', 'KMerIndex', 'feed_single_ended_reads',
-           'feed_pair_ended_reads', 'NativeReadFeeder', 'ReadBatch')
+           'feed_pair_ended_reads', 'NativeReadFeeder', 'ReadBatch', 'PackedReads', 'PackedReadFeeder')
 
 INVALID_INDEX = 0x7FFFFFFF          # seekmer/_common.pxd:10
 BUFFER_SIZE = 65536                 # seekmer/common.py:16
@@ -444,3 +444,205 @@ class NativeReadFeeder:
                 if process.poll() is None:
                     process.terminate()
                 process.wait()
+
+
+# ------------------------------------------------------------- packed pieces
+class PackedReads:
+    """Reads as the mapper takes them: 2-bit code words (32 bases per uint64, first base in the top
+    two bits; seekmer/_kmer.pxd:253-273), lengths, and -- only for reads that hold a character
+    other than upper-case ACGT -- the bit plane the SIFT4 checks need (seekmer/_mapper.pyx:500-501).
+    ``stream`` 0 = single-end reads or mate 1, 1 = mate 2; ``first_read`` = the unit reads[0]
+    belongs to.  Wraps an ``skm_packed_reads`` whose arrays belong to a native reader (valid until
+    the reader's next piece) or to numpy arrays kept alive here."""
+
+    __slots__ = ('raw', '_keep', 'paired')
+
+    def __init__(self, raw, keep=None, paired=None):
+        self.raw = raw
+        self._keep = keep
+        self.paired = bool(raw.stream) if paired is None else bool(paired)    # one of two streams?
+
+    stream = property(lambda self: self.raw.stream)
+    first_read = property(lambda self: self.raw.first_read)
+    n_reads = property(lambda self: self.raw.n_reads)
+    code_words = property(lambda self: self.raw.code_words)
+    uniform_len = property(lambda self: self.raw.uniform_len if self.raw.uniform_len >= 0 else None)
+
+    @staticmethod
+    def _view(pointer, count, ctype, dtype):
+        if not pointer or count <= 0:
+            return numpy.zeros(0, dtype=dtype)
+        return numpy.frombuffer((ctype * count).from_address(pointer), dtype=dtype)
+
+    @property
+    def codes(self):
+        """uint64[n_reads, code_words] (a view)"""
+        r = self.raw
+        flat = self._view(r.codes, (r.n_reads - 1) * r.read_stride + r.code_words if r.n_reads else 0,
+                          ctypes.c_uint64, numpy.uint64)
+        if r.n_reads == 0:
+            return flat.reshape(0, max(r.code_words, 1))
+        return numpy.lib.stride_tricks.as_strided(flat, (r.n_reads, r.code_words), (8 * r.read_stride, 8),
+                                                  writeable=False)
+
+    @property
+    def lengths(self):
+        r = self.raw
+        if r.lengths:
+            return self._view(r.lengths, r.n_reads, ctypes.c_uint32, numpy.uint32)
+        return numpy.full(r.n_reads, r.uniform_len, dtype=numpy.uint32)
+
+    @property
+    def exceptions(self):
+        """(read indices uint32[n], bit planes uint32[n, code_words])"""
+        r = self.raw
+        reads = self._view(r.exception_reads, r.n_exceptions, ctypes.c_uint32, numpy.uint32)
+        masks = self._view(r.exception_masks, r.n_exceptions * r.code_words, ctypes.c_uint32, numpy.uint32)
+        return reads, masks.reshape(r.n_exceptions, max(r.code_words, 1))
+
+    @property
+    def names(self):
+        r = self.raw
+        if not r.name_offsets:
+            return None
+        offsets = self._view(r.name_offsets, r.n_reads + 1, ctypes.c_int64, numpy.int64)
+        raw = ctypes.string_at(r.names, int(offsets[-1])) if offsets[-1] else b''
+        return [raw[offsets[i]:offsets[i + 1]] for i in range(r.n_reads)]
+
+    def copy(self):
+        """The same piece over arrays of its own."""
+        return PackedReads.from_arrays(self.stream, self.first_read, numpy.array(self.codes), numpy.array(self.lengths),
+                                       *[numpy.array(a) for a in self.exceptions], paired=self.paired)
+
+    @classmethod
+    def from_arrays(cls, stream, first_read, codes, lengths, exception_reads=None, exception_masks=None,
+                    paired=None):
+        codes = numpy.ascontiguousarray(codes, dtype=numpy.uint64)
+        if codes.ndim != 2:
+            raise ValueError('codes must be [n_reads, code_words]')
+        lengths = numpy.ascontiguousarray(lengths, dtype=numpy.uint32)
+        n_reads, code_words = codes.shape
+        if lengths.shape != (n_reads,):
+            raise ValueError('one length per read')
+        if exception_reads is None:
+            exception_reads = numpy.zeros(0, dtype=numpy.uint32)
+            exception_masks = numpy.zeros((0, code_words), dtype=numpy.uint32)
+        exception_reads = numpy.ascontiguousarray(exception_reads, dtype=numpy.uint32)
+        exception_masks = numpy.ascontiguousarray(exception_masks, dtype=numpy.uint32).reshape(-1, max(code_words, 1))
+        raw = _native.PackedReads()
+        raw.stream, raw.code_words, raw.first_read, raw.n_reads = int(stream), code_words, int(first_read), n_reads
+        raw.read_stride = code_words
+        raw.uniform_len = int(lengths[0]) if n_reads and (lengths == lengths[0]).all() else -1
+        raw.codes = codes.ctypes.data
+        raw.lengths = lengths.ctypes.data
+        raw.n_exceptions = exception_reads.size
+        raw.exception_reads = exception_reads.ctypes.data if exception_reads.size else None
+        raw.exception_masks = exception_masks.ctypes.data if exception_reads.size else None
+        return cls(raw, keep=(codes, lengths, exception_reads, exception_masks), paired=paired)
+
+    @classmethod
+    def from_ascii(cls, bases, offsets, stream=0, first_read=0, variant=-1, paired=None):
+        """Pack reads held as bases back to back + offsets (skm_pack_reads)."""
+        offsets = numpy.ascontiguousarray(offsets, dtype=numpy.int64)
+        bases = numpy.ascontiguousarray(bases, dtype=numpy.uint8)
+        n_reads = offsets.size - 1
+        longest = int(numpy.diff(offsets).max()) if n_reads else 0
+        code_words = max(1, (longest + 31) // 32)
+        codes = numpy.zeros((n_reads, code_words), dtype=numpy.uint64)
+        lengths = numpy.zeros(n_reads, dtype=numpy.uint32)
+        cap = 1024
+        while True:
+            exc_reads = numpy.zeros(cap, dtype=numpy.uint32)
+            exc_masks = numpy.zeros((cap, code_words), dtype=numpy.uint32)
+            n_exc = ctypes.c_int64()
+            code = _native.host().skm_pack_reads(
+                bases.ctypes.data, _native.ptr(offsets, _native.c_i64p), n_reads, code_words, codes.ctypes.data,
+                lengths.ctypes.data, exc_reads.ctypes.data, exc_masks.ctypes.data, cap, ctypes.byref(n_exc), variant)
+            if code == _native.SKM_ERR_STATE and n_exc.value > cap:
+                cap = n_exc.value
+                continue
+            _native.check_host(code, 'skm_pack_reads')
+            break
+        return cls.from_arrays(stream, first_read, codes, lengths, exc_reads[:n_exc.value], exc_masks[:n_exc.value],
+                               paired=paired)
+
+
+class PackedReadFeeder:
+    """Plain FASTQ files straight to PackedReads pieces in one pass over the text
+    (skm_fastq_packed_*): the reference's feeders (seekmer/common.py:126-197) for the mapper's own
+    input format.  Pieces of a paired sample come as two streams (mate 1 files, mate 2 files), each
+    numbered by unit; a piece is valid until the next one is asked for (``copy()`` keeps it).
+    ``eligible(paths)``: plain files only -- compressed inputs go through NativeReadFeeder."""
+
+    def __init__(self, paths, paired, threads=0, chunk_bytes=0, pinned=False, want_names=False):
+        paths = [pathlib.Path(p) for p in paths]
+        if paired and len(paths) % 2 != 0:
+            raise ValueError('cannot process odd numbers of pair-ended files')
+        self.paths = paths
+        self.paired = bool(paired)
+        self.threads = int(threads)
+        self.chunk_bytes = int(chunk_bytes)
+        self.pinned = bool(pinned)
+        self.want_names = bool(want_names)
+        self.stats = None
+
+    @staticmethod
+    def eligible(paths):
+        return all(pathlib.Path(p).suffix not in ('.gz', '.bz2', '.xz', '.lzma') and pathlib.Path(p).is_file()
+                   for p in paths)
+
+    def open(self):
+        """The native reader (an skm_fastq_packed handle owner) for callers that drain it natively."""
+        return _PackedReader(self)
+
+    def __iter__(self):
+        reader = self.open()
+        try:
+            while True:
+                piece = reader.next()
+                if piece is None:
+                    break
+                yield piece
+        finally:
+            self.stats = reader.stats()
+            reader.close()
+
+
+class _PackedReader:
+    def __init__(self, feeder):
+        self.paired = feeder.paired
+        host = _native.host()
+        names = [str(p).encode() for p in feeder.paths]
+        array = (ctypes.c_char_p * len(names))(*names)
+        self.handle = ctypes.c_void_p()
+        _native.check_host(host.skm_fastq_packed_open(
+            array, len(names), int(feeder.paired), feeder.threads, feeder.chunk_bytes, int(feeder.want_names),
+            ctypes.byref(self.handle)), 'skm_fastq_packed_open')
+        if feeder.pinned:
+            hip = _native.hip()
+            _native.check_host(host.skm_fastq_packed_set_allocator(
+                self.handle, ctypes.cast(hip.skm_pinned_alloc, ctypes.c_void_p),
+                ctypes.cast(hip.skm_pinned_free, ctypes.c_void_p)), 'skm_fastq_packed_set_allocator')
+
+    def next(self):
+        raw = _native.PackedReads()
+        _native.check_host(_native.host().skm_fastq_packed_next(self.handle, ctypes.byref(raw)),
+                           'skm_fastq_packed_next')
+        return PackedReads(raw, keep=self, paired=self.paired) if raw.n_reads else None
+
+    def stats(self):
+        out = (ctypes.c_int64 * 8)()
+        _native.check_host(_native.host().skm_fastq_packed_stats(self.handle, out), 'skm_fastq_packed_stats')
+        return {'accepted': out[0], 'reparsed': out[1], 'reads': out[2], 'exceptions': out[3], 'variant': out[4],
+                'units': out[5]}
+
+    def close(self):
+        if self.handle:
+            _native.host().skm_fastq_packed_close(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

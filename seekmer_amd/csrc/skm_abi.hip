@@ -13,7 +13,10 @@
 #include <cstring>
 #include <chrono>
 #include <condition_variable>
+#include <atomic>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <numeric>
@@ -172,6 +175,27 @@ struct skm_mapper {
     uint64_t job_error_ticket = 0;
     std::string job_error_msg;
     DBuf<unsigned long long> scan_out;        // device-side max read length / monotonicity of a batch
+    // ---- packed pieces (skm_mapper_push_packed): reads that arrive as 2-bit code words wait in HBM,
+    // one ascending list of pieces per stream, until the worker maps a run of units that every
+    // stream covers.  All of it under q_mu.
+    struct Piece {
+        int64_t first = 0, n = 0;             // units [first, first + n) of the stream (what is left of the piece)
+        int64_t origin = 0;                   // first_read of the piece as pushed: the arrays start there
+        int cw = 1;
+        int64_t uniform_len = -1;
+        std::shared_ptr<char> block;          // one HBM allocation: codes | lengths | exception reads | masks
+        uint64_t *codes = nullptr;            // [n as pushed][cw]
+        uint32_t *lengths = nullptr;          // or NULL (uniform_len)
+        uint32_t *exc_reads_dev = nullptr, *exc_masks = nullptr;
+        std::vector<uint32_t> exc_reads;      // host copy (indices relative to origin), for cutting runs
+        bool in_job = false;
+    };
+    std::deque<Piece> pending[2];
+    hipStream_t packed_stream = nullptr;
+    int packed_paired = -1;                   // -1 until the first piece
+    int packed_flush = 0;                     // callers waiting for everything mappable to be mapped
+    bool packed_busy = false;
+    int64_t packed_dropped = 0;               // reads that never got a mate
     int vote[8] = {1, 1, 1, 1, 1, 1, 1, 0};   // quorum per action (start, lookup, merge, left, right, emit, scan)
 };
 
@@ -268,11 +292,29 @@ extern "C" int skm_device_synchronize(int device)
 // Page-locked host memory: a batch handed over from it crosses the link at the full PCIe rate
 // and asynchronously (no staging copy by the runtime).  Plain C allocator signatures so that
 // libseekmer_host.so's FASTQ reader can take them as its slab allocator (skm_fastq_set_allocator).
+namespace { std::atomic<int> g_pinned_device{0}; }
+
+extern "C" int skm_pinned_set_device(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(SKM_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= count) return fail(SKM_ERR_ARG, "no GPU %d", device);
+    g_pinned_device.store(device);
+    return SKM_OK;
+}
+
+// (called from the FASTQ readers' worker threads, which never chose a device: page-lock against the
+// process's GPU, not against GPU 0, and portably, so that any device of the process may copy from it)
 extern "C" void *skm_pinned_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
-    return p;
+    const int want = g_pinned_device.load();
+    int current = 0;
+    if (hipGetDevice(&current) != hipSuccess) return nullptr;
+    if (current != want && hipSetDevice(want) != hipSuccess) return nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (current != want) (void)hipSetDevice(current);
+    return e == hipSuccess ? p : nullptr;
 }
 
 extern "C" void skm_pinned_free(void *p)
@@ -622,8 +664,12 @@ int read_error(skm_mapper *m)
 
 // first_unit: global index of the batch's first unit (first-seen values count from it), or -1
 // to continue after the units mapped so far
+// fill_records: what makes the read records of the batch (records, words per read, u32 words per
+// record); nullptr = pack_reads_kernel over ASCII bases + offsets
+typedef std::function<int(uint32_t *, int, int)> RecordStage;
 int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_offsets,
-                       int64_t n_units, int paired, int max_len, int64_t first_unit = -1)
+                       int64_t n_units, int paired, int max_len, int64_t first_unit = -1,
+                       const RecordStage *fill_records = nullptr)
 {
     const int64_t unit_base = first_unit >= 0 ? first_unit : m->units_done;
     skm_index *ix = m->ix;
@@ -689,7 +735,8 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     for (int i = 0; i < 8; ++i) b.vote[i] = m->vote[i];
 
     HIP_TRY(hipEventRecord(m->ev[0], m->stream));
-    launch_pack_reads(d_bases, d_offsets, n_reads, words, record_words, m->records.p, m->stream);
+    if (fill_records) SKM_TRY((*fill_records)(m->records.p, words, record_words));
+    else launch_pack_reads(d_bases, d_offsets, n_reads, words, record_words, m->records.p, m->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev[1], m->stream));
     unsigned long long ids = 0;
@@ -741,6 +788,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         const int err = *reinterpret_cast<int *>(m->pinned + 16);
         if (err == SKM_ERR_COLLISION)
             return fail(SKM_ERR_COLLISION, "two different class tuples share a 64-bit key");
+        if (err == SKM_ERR_ARG) return fail(SKM_ERR_ARG, "a packed read is longer than its code words hold");
         if (err) return fail(err, "class table kernel reported error %d", err);
         m->host_arena_used = (int64_t)m->pinned[CTR_ARENA];
         m->host_classes = (int64_t)m->pinned[CTR_CLASSES];
@@ -802,6 +850,8 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
         lane.bases.release();
         lane.offsets.release();
     }
+    for (auto &list : m->pending) list.clear();
+    if (m->packed_stream) { (void)hipStreamSynchronize(m->packed_stream); (void)hipStreamDestroy(m->packed_stream); }
     m->scan_out.release();
     m->slots.release(); m->arena.release(); m->class_list.release();
     m->counters.release();
@@ -840,19 +890,186 @@ int run_job(skm_mapper *m, const skm_mapper::Job &job)
                               job.first_unit);
 }
 
+// ---- packed pieces ----------------------------------------------------------------------
+constexpr int64_t PACKED_MIN_UNITS = 1 << 15;      // smaller runs wait for more (or for a flush)
+constexpr int64_t PACKED_MAX_UNITS = 1 << 21;      // one launch
+
+// (q_mu held) the first run of units that every stream covers: [*lo, *hi), at most PACKED_MAX_UNITS
+bool packed_find_run(skm_mapper *m, int64_t *lo, int64_t *hi)
+{
+    const auto &a = m->pending[0];
+    if (a.empty()) return false;
+    if (m->packed_paired != 1) {
+        *lo = a.front().first;
+        *hi = *lo;
+        for (const auto &piece : a) {
+            if (piece.first != *hi) break;
+            *hi += piece.n;
+            if (*hi - *lo >= PACKED_MAX_UNITS) { *hi = *lo + PACKED_MAX_UNITS; break; }
+        }
+        return *hi > *lo;
+    }
+    const auto &b = m->pending[1];
+    size_t i = 0, j = 0;
+    bool open = false;
+    while (i < a.size() && j < b.size()) {
+        const int64_t from = std::max(a[i].first, b[j].first);
+        const int64_t to = std::min(a[i].first + a[i].n, b[j].first + b[j].n);
+        if (from < to) {
+            if (!open) { *lo = from; *hi = to; open = true; }
+            else if (from == *hi) *hi = to;
+            else break;
+            if (*hi - *lo >= PACKED_MAX_UNITS) { *hi = *lo + PACKED_MAX_UNITS; break; }
+        }
+        if (a[i].first + a[i].n <= b[j].first + b[j].n) ++i; else ++j;
+    }
+    return open;
+}
+
+// (q_mu held) forget units [lo, hi) of a stream: they have been mapped.  What a piece holds
+// before `lo` (reads whose mates have not arrived yet) and after `hi` stays, sharing the block.
+void packed_consume(skm_mapper *m, int stream, int64_t lo, int64_t hi)
+{
+    auto &list = m->pending[stream];
+    std::deque<skm_mapper::Piece> kept;
+    for (auto &piece : list) {
+        piece.in_job = false;
+        const int64_t end = piece.first + piece.n;
+        if (end <= lo || piece.first >= hi) { kept.push_back(std::move(piece)); continue; }
+        if (piece.first < lo) {
+            skm_mapper::Piece head = piece;
+            head.n = lo - piece.first;
+            kept.push_back(std::move(head));
+        }
+        if (end > hi) {
+            skm_mapper::Piece tail = piece;
+            tail.first = hi;
+            tail.n = end - hi;
+            kept.push_back(std::move(tail));
+        }
+    }
+    list.swap(kept);
+}
+
+// (q_mu held) nothing more can be mapped: reads without a mate go
+void packed_drop_all(skm_mapper *m)
+{
+    for (auto &list : m->pending) {
+        for (auto &piece : list) m->packed_dropped += piece.n;
+        list.clear();
+    }
+}
+
+struct PackedSegment {               // part of one piece inside a run
+    int mate;
+    int64_t first, n;                // units
+    const uint64_t *codes;
+    const uint32_t *lengths;
+    int cw;
+    uint32_t uniform_len;
+    const uint32_t *exc_reads, *exc_masks;   // device, already offset to the segment's first exception
+    int64_t n_exc;
+    int64_t exc_base;                // index (relative to the piece as pushed) of the segment's first read
+};
+
+int run_packed_job(skm_mapper *m, int64_t lo, int64_t hi, int paired, const std::vector<PackedSegment> &segments,
+                   int max_cw)
+{
+    std::lock_guard<std::mutex> lock(m->mu);
+    SKM_TRY(set_device(m->ix->device));
+    const int mates = paired ? 2 : 1;
+    const RecordStage fill = [&](uint32_t *records, int words, int record_words) -> int {
+        for (const PackedSegment &seg : segments) {
+            uint32_t *dst = records + ((seg.first - lo) * mates + seg.mate) * (int64_t)record_words;
+            launch_unpack_reads(seg.codes, seg.cw, seg.cw, seg.lengths, seg.uniform_len, seg.n, words, dst,
+                                (int64_t)mates * record_words, m->error.p, m->stream);
+            if (seg.n_exc)
+                launch_unpack_exceptions(seg.exc_reads, seg.exc_masks, seg.n_exc, seg.cw, seg.exc_base, words, dst,
+                                         (int64_t)mates * record_words, m->stream);
+        }
+        HIP_TRY(hipGetLastError());
+        return SKM_OK;
+    };
+    return map_batch_resident(m, nullptr, nullptr, hi - lo, paired, max_cw * 32, lo, &fill);
+}
+
 void worker_main(skm_mapper *m)
 {
     for (;;) {
         skm_mapper::Job job;
+        bool packed = false;
+        int64_t lo = 0, hi = 0;
+        int paired = 0, max_cw = 1;
+        std::vector<PackedSegment> segments;
         {
             std::unique_lock<std::mutex> hold(m->q_mu);
-            m->q_cv.wait(hold, [&] { return m->stop || !m->jobs.empty(); });
-            if (m->jobs.empty()) return;          // stop requested and nothing left
-            job = m->jobs.front();
-            m->jobs.pop_front();
+            for (;;) {
+                if (!m->jobs.empty()) break;
+                if (m->job_error != SKM_OK && (!m->pending[0].empty() || !m->pending[1].empty())) {
+                    packed_drop_all(m);         // after a failure the table is not to be trusted
+                    m->done_cv.notify_all();
+                }
+                if (packed_find_run(m, &lo, &hi) && (hi - lo >= PACKED_MIN_UNITS || m->packed_flush || m->stop)) {
+                    packed = true;
+                    break;
+                }
+                if ((m->packed_flush || m->stop) && (!m->pending[0].empty() || !m->pending[1].empty())) {
+                    packed_drop_all(m);
+                    m->done_cv.notify_all();
+                }
+                if (m->stop) return;            // stop requested and nothing left
+                m->q_cv.wait(hold);
+            }
+            if (!packed) {
+                job = m->jobs.front();
+                m->jobs.pop_front();
+            } else {
+                paired = m->packed_paired == 1;
+                for (int s = 0; s < (paired ? 2 : 1); ++s)
+                    for (auto &piece : m->pending[s]) {
+                        const int64_t from = std::max(lo, piece.first), to = std::min(hi, piece.first + piece.n);
+                        if (from >= to) continue;
+                        piece.in_job = true;
+                        PackedSegment seg{};
+                        seg.mate = s;
+                        seg.first = from;
+                        seg.n = to - from;
+                        const int64_t skip = from - piece.origin;
+                        seg.codes = piece.codes + skip * piece.cw;
+                        seg.lengths = piece.lengths ? piece.lengths + skip : nullptr;
+                        seg.cw = piece.cw;
+                        seg.uniform_len = (uint32_t)std::max<int64_t>(piece.uniform_len, 0);
+                        const auto e0 = std::lower_bound(piece.exc_reads.begin(), piece.exc_reads.end(), (uint32_t)skip);
+                        const auto e1 = std::lower_bound(piece.exc_reads.begin(), piece.exc_reads.end(), (uint32_t)(skip + seg.n));
+                        seg.n_exc = e1 - e0;
+                        const int64_t at = e0 - piece.exc_reads.begin();
+                        seg.exc_reads = piece.exc_reads_dev + at;
+                        seg.exc_masks = piece.exc_masks + at * piece.cw;
+                        seg.exc_base = skip;
+                        max_cw = std::max(max_cw, piece.cw);
+                        segments.push_back(seg);
+                    }
+                m->packed_busy = true;
+            }
         }
         int rc = SKM_OK;
         std::string message;
+        if (packed) {
+            rc = run_packed_job(m, lo, hi, paired, segments, max_cw);
+            if (rc != SKM_OK) message = g_error;
+            {
+                std::lock_guard<std::mutex> hold(m->q_mu);
+                if (rc != SKM_OK && m->job_error == SKM_OK) {
+                    m->job_error = rc;
+                    m->job_error_ticket = 0;              // (reported by every wait)
+                    m->job_error_msg = message;
+                }
+                for (int s = 0; s < (paired ? 2 : 1); ++s) packed_consume(m, s, lo, hi);
+                m->packed_busy = false;
+            }
+            m->done_cv.notify_all();
+            continue;
+        }
         bool skip;
         {
             std::lock_guard<std::mutex> hold(m->q_mu);
@@ -876,13 +1093,20 @@ void worker_main(skm_mapper *m)
     }
 }
 
-// wait until every queued batch up to `ticket` (0 = all) has been mapped; reports (and, with
-// `consume`, forgets) the first failure among them
+// wait until every queued batch up to `ticket` has been mapped (0 = all of them AND every packed
+// read that has a mate: what is left without one is dropped); reports (and, with `consume`,
+// forgets) the first failure among them
 int wait_jobs(skm_mapper *m, uint64_t ticket, bool consume)
 {
     std::unique_lock<std::mutex> hold(m->q_mu);
     const uint64_t upto = ticket ? ticket : m->next_ticket - 1;
     m->done_cv.wait(hold, [&] { return m->done_ticket >= upto; });
+    if (ticket == 0 && (m->packed_busy || !m->pending[0].empty() || !m->pending[1].empty())) {
+        m->packed_flush++;
+        m->q_cv.notify_all();
+        m->done_cv.wait(hold, [&] { return !m->packed_busy && m->pending[0].empty() && m->pending[1].empty(); });
+        m->packed_flush--;
+    }
     if (m->job_error != SKM_OK && m->job_error_ticket <= upto) {
         const int rc = m->job_error;
         const std::string message = m->job_error_msg;
@@ -970,6 +1194,106 @@ extern "C" int skm_mapper_sync(skm_mapper *m)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
     return wait_jobs(m, 0, true);
+}
+
+extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *piece, int paired)
+{
+    if (!m || !piece) return fail(SKM_ERR_ARG, "NULL argument");
+    const int64_t n = piece->n_reads;
+    const int cw = piece->code_words;
+    if (n < 0 || n >= (1LL << 31) || piece->first_read < 0) return fail(SKM_ERR_ARG, "bad piece: %lld reads from %lld", (long long)n, (long long)piece->first_read);
+    if (piece->stream < 0 || piece->stream > (paired ? 1 : 0)) return fail(SKM_ERR_ARG, "stream %d of a %s sample", piece->stream, paired ? "paired" : "single-ended");
+    if (n == 0) return SKM_OK;
+    if (cw < 1 || cw > (1 << 15) || piece->read_stride < cw || !piece->codes) return fail(SKM_ERR_ARG, "bad code words");
+    if (piece->uniform_len < 0 && !piece->lengths) return fail(SKM_ERR_ARG, "lengths is NULL");
+    if (piece->uniform_len > 32LL * cw) return fail(SKM_ERR_ARG, "reads of %lld bases in %d code words", (long long)piece->uniform_len, cw);
+    const int64_t n_exc = piece->n_exceptions;
+    if (n_exc < 0 || n_exc > n || (n_exc > 0 && (!piece->exception_reads || !piece->exception_masks)))
+        return fail(SKM_ERR_ARG, "bad exception list");
+    for (int64_t e = 0; e < n_exc; ++e)
+        if (piece->exception_reads[e] >= (uint64_t)n || (e && piece->exception_reads[e] <= piece->exception_reads[e - 1]))
+            return fail(SKM_ERR_ARG, "exception reads must ascend and lie inside the piece");
+    SKM_TRY(set_device(m->ix->device));
+    {
+        std::lock_guard<std::mutex> hold(m->q_mu);
+        if (m->packed_paired >= 0 && m->packed_paired != (paired ? 1 : 0) && (!m->pending[0].empty() || !m->pending[1].empty() || m->packed_busy))
+            return fail(SKM_ERR_STATE, "paired and single-ended pieces in one run");
+        m->packed_paired = paired ? 1 : 0;
+        if (!m->packed_stream) HIP_TRY(hipStreamCreateWithFlags(&m->packed_stream, hipStreamNonBlocking));
+    }
+    // one HBM block: codes | lengths | exception reads | exception bit planes
+    const bool uniform = piece->uniform_len >= 0;
+    auto round = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t codes_bytes = round((size_t)n * cw * 8);
+    const size_t len_bytes = uniform ? 0 : round((size_t)n * 4);
+    const size_t exc_bytes = round((size_t)n_exc * 4), mask_bytes = round((size_t)n_exc * cw * 4);
+    char *raw = nullptr;
+    HIP_TRY(pool_alloc((void **)&raw, codes_bytes + len_bytes + exc_bytes + mask_bytes + 256));
+    skm_mapper::Piece held;
+    held.block = std::shared_ptr<char>(raw, [](char *q) { pool_free(q); });
+    held.first = held.origin = piece->first_read;
+    held.n = n;
+    held.cw = cw;
+    held.uniform_len = uniform ? piece->uniform_len : -1;
+    held.codes = (uint64_t *)raw;
+    held.lengths = uniform ? nullptr : (uint32_t *)(raw + codes_bytes);
+    held.exc_reads_dev = (uint32_t *)(raw + codes_bytes + len_bytes);
+    held.exc_masks = (uint32_t *)(raw + codes_bytes + len_bytes + exc_bytes);
+    if (n_exc) held.exc_reads.assign(piece->exception_reads, piece->exception_reads + n_exc);
+    hipStream_t stream = m->packed_stream;
+    if (piece->read_stride == cw)
+        HIP_TRY(hipMemcpyAsync(held.codes, piece->codes, (size_t)n * cw * 8, hipMemcpyHostToDevice, stream));
+    else
+        HIP_TRY(hipMemcpy2DAsync(held.codes, (size_t)cw * 8, piece->codes, (size_t)piece->read_stride * 8, (size_t)cw * 8,
+                                 (size_t)n, hipMemcpyHostToDevice, stream));
+    if (!uniform) HIP_TRY(hipMemcpyAsync(held.lengths, piece->lengths, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    if (n_exc) {
+        HIP_TRY(hipMemcpyAsync(held.exc_reads_dev, piece->exception_reads, (size_t)n_exc * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(held.exc_masks, piece->exception_masks, (size_t)n_exc * cw * 4, hipMemcpyHostToDevice, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));        // (the caller's arrays are free again)
+    {
+        std::lock_guard<std::mutex> hold(m->q_mu);
+        if (!m->worker_started) {
+            m->worker = std::thread(worker_main, m);
+            m->worker_started = true;
+        }
+        auto &list = m->pending[piece->stream];
+        // a piece that overlaps what its stream holds replaces the reads from its first one on
+        bool overlaps = false;
+        for (const auto &other : list)
+            if (other.first < held.first + held.n && held.first < other.first + other.n) overlaps = true;
+        if (overlaps) {
+            for (const auto &other : list)
+                if (other.in_job && other.first + other.n > held.first)
+                    return fail(SKM_ERR_STATE, "a piece replaces reads that are being mapped");
+            while (!list.empty() && list.back().first >= held.first) list.pop_back();
+            if (!list.empty() && list.back().first + list.back().n > held.first) list.back().n = held.first - list.back().first;
+            list.push_back(std::move(held));
+        } else {
+            size_t at = list.size();
+            while (at > 0 && list[at - 1].first > held.first) --at;
+            list.insert(list.begin() + (long)at, std::move(held));
+        }
+    }
+    m->q_cv.notify_all();
+    return SKM_OK;
+}
+
+extern "C" int skm_mapper_map_packed_source(skm_mapper *m, skm_packed_source next, void *context, int paired,
+                                            int64_t *n_pieces)
+{
+    if (!m || !next) return fail(SKM_ERR_ARG, "NULL argument");
+    if (n_pieces) *n_pieces = 0;
+    for (;;) {
+        skm_packed_reads piece;
+        memset(&piece, 0, sizeof(piece));
+        const int rc = next(context, &piece);
+        if (rc != SKM_OK) return fail(rc, "the source of packed reads failed (%d)", rc);
+        if (piece.n_reads == 0) return SKM_OK;
+        SKM_TRY(skm_mapper_push_packed(m, &piece, paired));
+        if (n_pieces) ++*n_pieces;
+    }
 }
 
 extern "C" int skm_mapper_map_batch(skm_mapper *m, const char *bases, const int64_t *offsets,

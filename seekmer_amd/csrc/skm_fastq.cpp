@@ -18,6 +18,7 @@
 // Slabs come from an allocator the caller may replace (skm_fastq_set_allocator): with
 // page-locked memory (skm_pinned_alloc) a batch goes over PCIe by DMA straight from the slab.
 #include "../../include/seekmer_hip.h"
+#include "skm_fastq_shared.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -35,6 +36,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+using namespace skmfq;
 
 namespace {
 
@@ -95,44 +98,6 @@ inline void strip(const char *&p, size_t &n)
     while (n && is_space(p[n - 1])) --n;
 }
 
-typedef void *(*alloc_fn)(size_t);
-typedef void (*free_fn)(void *);
-
-// growable array in memory of the slab's allocator
-template <class T>
-struct Buf {
-    T *p = nullptr;
-    size_t n = 0, cap = 0;
-    alloc_fn al = malloc;
-    free_fn fr = free;
-    bool failed = false;
-
-    void reserve(size_t want)
-    {
-        if (want <= cap) return;
-        size_t grown = std::max(want, cap + cap / 2 + 1024);
-        T *q = (T *)al(grown * sizeof(T));
-        if (!q) { failed = true; return; }
-        if (n) memcpy(q, p, n * sizeof(T));
-        if (p) fr(p);
-        p = q;
-        cap = grown;
-    }
-    void append(const T *src, size_t count)
-    {
-        if (n + count > cap) { reserve(n + count); if (failed) return; }
-        memcpy(p + n, src, count * sizeof(T));
-        n += count;
-    }
-    void push(T v)
-    {
-        if (n + 1 > cap) { reserve(n + 1); if (failed) return; }
-        p[n++] = v;
-    }
-    void clear() { n = 0; }
-    void release() { if (p) fr(p); p = nullptr; n = cap = 0; }
-};
-
 }  // namespace
 
 // The four arrays of one batch.  Slabs are recycled: touching fresh pages is
@@ -176,14 +141,19 @@ std::mutex g_spare_lock;
 std::vector<skm_fastq_slab *> g_spare;
 constexpr size_t MAX_SPARE = 32;
 
-constexpr size_t BLOCK = 1 << 20;          // granularity of the newline index
+}  // namespace
 
-// Mappings outlive their reader.  Setting up and tearing down the page tables of a multi-gigabyte
-// text file costs more than parsing it (4.4 GB: ~50 ms of faults, ~100 ms of munmap with the
-// process's memory-map lock held -- the quantification that follows a mapping run stalled on
-// exactly that), so a mapping is kept, keyed by the file's identity, for the next reader of the
-// same file; mappings nobody uses are dropped oldest first beyond MAP_KEEP_BYTES, in the
-// background and in pieces.
+// ---- the process-wide cache of file mappings (skm_fastq_shared.h) ------------------------
+// Setting up and tearing down the page tables of a multi-gigabyte text file costs more than
+// parsing it (4.4 GB: ~50 ms of faults, ~100 ms of munmap with the process's memory-map lock
+// held -- the quantification that follows a mapping run stalled on exactly that), so a mapping
+// is shared by the readers that have the same file open at the same time and torn down in the
+// background and in pieces.  A caller that reads the same files again and again (a benchmark's
+// passes, a service) may let unused mappings stay cached up to a budget
+// (skm_fastq_cache_bytes); the default keeps nothing: a file replaced or truncated in place
+// must not be read through a stale mapping by the next sample.
+namespace skmfq {
+namespace {
 struct MapEntry {
     std::string path;
     dev_t dev; ino_t ino; off_t size; long mtime_s, mtime_ns;
@@ -194,7 +164,7 @@ struct MapEntry {
 std::mutex g_map_lock;
 std::vector<MapEntry> g_maps;
 uint64_t g_map_stamp = 0;
-constexpr size_t MAP_KEEP_BYTES = 64ull << 30;
+size_t g_map_keep_bytes = 0;
 
 void unmap_in_pieces(const char *p, size_t n)
 {
@@ -205,86 +175,104 @@ void unmap_in_pieces(const char *p, size_t n)
     }
 }
 
-struct Mapped {
-    const char *p = nullptr;
-    size_t n = 0;
-    int64_t lines = 0;                     // lines of the file (a last line without '\n' counts)
-    std::vector<int64_t> before;           // before[b] = newlines in [0, b * BLOCK)
+// (g_map_lock held) unused mappings beyond the budget, oldest first
+void collect_droppable(std::vector<std::pair<const char *, size_t>> &drop)
+{
+    size_t kept = 0;
+    for (auto &e : g_maps) if (e.users == 0) kept += (size_t)e.size;
+    while (kept > g_map_keep_bytes) {
+        int oldest = -1;
+        for (size_t i = 0; i < g_maps.size(); ++i)
+            if (g_maps[i].users == 0 && (oldest < 0 || g_maps[i].stamp < g_maps[(size_t)oldest].stamp)) oldest = (int)i;
+        if (oldest < 0) break;
+        drop.emplace_back(g_maps[(size_t)oldest].p, (size_t)g_maps[(size_t)oldest].size);
+        kept -= (size_t)g_maps[(size_t)oldest].size;
+        g_maps.erase(g_maps.begin() + oldest);
+    }
+}
 
-    bool map(const char *path)
-    {
-        const int fd = open(path, O_RDONLY);
-        if (fd < 0) return false;
-        struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
-        n = (size_t)st.st_size;
-        if (n) {
-            std::lock_guard<std::mutex> hold(g_map_lock);
-            for (auto &e : g_maps)
-                if (e.dev == st.st_dev && e.ino == st.st_ino && e.size == st.st_size
-                        && e.mtime_s == (long)st.st_mtim.tv_sec && e.mtime_ns == (long)st.st_mtim.tv_nsec) {
-                    e.users++;
-                    e.stamp = ++g_map_stamp;
-                    p = e.p;
-                    close(fd);
-                    return true;
-                }
-            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) { close(fd); return false; }
-            (void)madvise(m, n, MADV_WILLNEED);
-            p = (const char *)m;
-            g_maps.push_back(MapEntry{path, st.st_dev, st.st_ino, st.st_size, (long)st.st_mtim.tv_sec,
-                                      (long)st.st_mtim.tv_nsec, p, 1, ++g_map_stamp});
-        }
-        close(fd);
-        return true;
-    }
-    // give the mapping back: it stays cached; what exceeds the budget goes in the background
-    void unmap()
-    {
-        if (!p) return;
-        std::vector<std::pair<const char *, size_t>> drop;
-        {
-            std::lock_guard<std::mutex> hold(g_map_lock);
-            size_t kept = 0;
-            for (auto &e : g_maps) {
-                if (e.p == p && e.users > 0) e.users--;
-                kept += (size_t)e.size;
-            }
-            while (kept > MAP_KEEP_BYTES) {
-                int oldest = -1;
-                for (size_t i = 0; i < g_maps.size(); ++i)
-                    if (g_maps[i].users == 0 && (oldest < 0 || g_maps[i].stamp < g_maps[(size_t)oldest].stamp)) oldest = (int)i;
-                if (oldest < 0) break;
-                drop.emplace_back(g_maps[(size_t)oldest].p, (size_t)g_maps[(size_t)oldest].size);
-                kept -= (size_t)g_maps[(size_t)oldest].size;
-                g_maps.erase(g_maps.begin() + oldest);
-            }
-        }
-        if (!drop.empty())
-            std::thread([drop]() { for (auto &d : drop) unmap_in_pieces(d.first, d.second); }).detach();
-        p = nullptr;
-        n = 0;
-    }
+void drop_in_background(std::vector<std::pair<const char *, size_t>> drop)
+{
+    if (!drop.empty())
+        std::thread([drop]() { for (auto &d : drop) unmap_in_pieces(d.first, d.second); }).detach();
+}
+}  // namespace
 
-    // byte offset where line `line` starts (line <= lines; line == lines -> end of file)
-    size_t line_start(int64_t line) const
+void set_map_keep_bytes(size_t bytes)
+{
+    std::vector<std::pair<const char *, size_t>> drop;
     {
-        if (line <= 0) return 0;
-        if (line >= lines) return n;
-        // the last block with fewer than `line` newlines before it
-        size_t b = (size_t)(std::lower_bound(before.begin(), before.end(), line) - before.begin()) - 1;
-        int64_t seen = before[b];
-        size_t at = b * BLOCK;
-        while (seen < line) {
-            const char *nl = (const char *)memchr(p + at, '\n', n - at);
-            if (!nl) return n;
-            at = (size_t)(nl - p) + 1;
-            ++seen;
-        }
-        return at;
+        std::lock_guard<std::mutex> hold(g_map_lock);
+        g_map_keep_bytes = bytes;
+        collect_droppable(drop);
     }
-};
+    drop_in_background(drop);
+}
+
+bool Mapped::map(const char *path)
+{
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
+    n = (size_t)st.st_size;
+    if (n) {
+        std::lock_guard<std::mutex> hold(g_map_lock);
+        for (auto &e : g_maps)
+            if (e.dev == st.st_dev && e.ino == st.st_ino && e.size == st.st_size
+                    && e.mtime_s == (long)st.st_mtim.tv_sec && e.mtime_ns == (long)st.st_mtim.tv_nsec) {
+                e.users++;
+                e.stamp = ++g_map_stamp;
+                p = e.p;
+                close(fd);
+                return true;
+            }
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); return false; }
+        (void)madvise(m, n, MADV_WILLNEED);
+        p = (const char *)m;
+        g_maps.push_back(MapEntry{path, st.st_dev, st.st_ino, st.st_size, (long)st.st_mtim.tv_sec,
+                                  (long)st.st_mtim.tv_nsec, p, 1, ++g_map_stamp});
+    }
+    close(fd);
+    return true;
+}
+
+void Mapped::unmap()
+{
+    if (!p) return;
+    std::vector<std::pair<const char *, size_t>> drop;
+    {
+        std::lock_guard<std::mutex> hold(g_map_lock);
+        for (auto &e : g_maps)
+            if (e.p == p && e.users > 0) { e.users--; break; }
+        collect_droppable(drop);
+    }
+    drop_in_background(drop);
+    p = nullptr;
+    n = 0;
+}
+
+size_t Mapped::line_start(int64_t line) const
+{
+    if (line <= 0) return 0;
+    if (line >= lines) return n;
+    // the last block with fewer than `line` newlines before it
+    size_t b = (size_t)(std::lower_bound(before.begin(), before.end(), line) - before.begin()) - 1;
+    int64_t seen = before[b];
+    size_t at = b * BLOCK;
+    while (seen < line) {
+        const char *nl = (const char *)memchr(p + at, '\n', n - at);
+        if (!nl) return n;
+        at = (size_t)(nl - p) + 1;
+        ++seen;
+    }
+    return at;
+}
+
+}  // namespace skmfq
+
+namespace {
 
 // (a byte-compare-and-add loop: the compiler turns it into 16/32-byte vector compares, an
 // order of magnitude faster than one memchr call per 100-byte line)

@@ -48,6 +48,16 @@ constexpr int MAP_CONTEXTS = 480;     // unit contexts per block: 16 words + 7 r
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
+// host-packed reads (skm_packed_reads) -> records: `n_reads` reads whose code words lie `stride`
+// u64 words apart go to dst, dst + dst_stride, ... (u32 words); *error = SKM_ERR_ARG when a length
+// exceeds 32 * code_words.  Then the bit planes of the exception reads (indices relative to
+// `first_read` of the same piece).
+void launch_unpack_reads(const uint64_t *codes, int64_t stride, int code_words, const uint32_t *lengths,
+                         uint32_t uniform_len, int64_t n_reads, int words_per_read, uint32_t *dst,
+                         int64_t dst_stride, int *error, hipStream_t stream);
+void launch_unpack_exceptions(const uint32_t *exc_reads, const uint32_t *exc_masks, int64_t n_exceptions,
+                              int code_words, int64_t first_read, int words_per_read, uint32_t *dst,
+                              int64_t dst_stride, hipStream_t stream);
 // out[0] = longest read, out[1] = places where the offsets step backwards; then offsets -= base
 void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,
                          hipStream_t stream);

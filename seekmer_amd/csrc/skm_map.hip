@@ -10,6 +10,7 @@
 // fetched from a 2-bit pool, the k-mer table is probed through a bucketised
 // device copy (skm_device.h: DevBucket), and the running target list of a unit
 // is never materialised: it is a slice of the index plus a keep-mask.
+#include "../../include/seekmer_hip.h"
 #include "skm_device.h"
 #include "skm_kernels.h"
 
@@ -116,6 +117,53 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
         reinterpret_cast<uint64_t *>(rec)[w] = c;
         rec[2 * words_per_read + w] = m;
         if (w == 0) rec[3 * words_per_read] = (uint32_t)len;
+    }
+}
+
+// ------------------------------------------------------------- unpack_reads
+// Reads that arrive already packed by the host (skm_packed_reads: code words only): one lane per
+// (read, record word) writes the 64-byte record the map kernel reads -- codes as they came, the
+// ACGT bit plane all ones up to the read's length, the length.  The destination stride places
+// mate m of every unit (paired batches interleave the mates: record 2 u + m).
+__global__ void __launch_bounds__(256)
+unpack_reads_kernel(const uint64_t *__restrict__ codes, int64_t stride, int code_words,
+                    const uint32_t *__restrict__ lengths, uint32_t uniform_len, int64_t n_reads,
+                    int words_per_read, uint32_t *__restrict__ dst, int64_t dst_stride, int *error)
+{
+    const int64_t total = n_reads * (int64_t)words_per_read;
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = total <= 0xffffffffLL ? (int64_t)((uint32_t)g / (uint32_t)words_per_read)
+                                                : g / words_per_read;
+        const int w = (int)(g - r * words_per_read);
+        uint32_t len = lengths ? lengths[r] : uniform_len;
+        if (len > 32u * (uint32_t)code_words) {           // (the host promised otherwise)
+            len = 32u * (uint32_t)code_words;
+            if (w == 0) atomicExch(error, SKM_ERR_ARG);
+        }
+        const uint64_t c = w < code_words ? codes[r * stride + w] : 0;
+        const int n = (int)len - 32 * w;
+        const uint32_t m = n >= 32 ? 0xffffffffu : (n <= 0 ? 0u : ~(0xffffffffu >> n));
+        uint32_t *rec = dst + r * dst_stride;
+        reinterpret_cast<uint64_t *>(rec)[w] = c;
+        rec[2 * words_per_read + w] = m;
+        if (w == 0) rec[3 * words_per_read] = len;
+    }
+}
+
+// the reads that hold a character other than upper-case ACGT get their own bit plane
+__global__ void __launch_bounds__(256)
+unpack_exceptions_kernel(const uint32_t *__restrict__ exc_reads, const uint32_t *__restrict__ exc_masks,
+                         int64_t n_exceptions, int code_words, int64_t first_read, int words_per_read,
+                         uint32_t *__restrict__ dst, int64_t dst_stride)
+{
+    const int64_t total = n_exceptions * (int64_t)code_words;
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = g / code_words;
+        const int w = (int)(g - e * code_words);
+        const int64_t r = (int64_t)exc_reads[e] - first_read;
+        if (w < words_per_read) dst[r * dst_stride + 2 * words_per_read + w] = exc_masks[g];
     }
 }
 
@@ -1380,6 +1428,30 @@ void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_r
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                        bases, offsets, n_reads, words_per_read, record_words, records);
+}
+
+void launch_unpack_reads(const uint64_t *codes, int64_t stride, int code_words, const uint32_t *lengths,
+                         uint32_t uniform_len, int64_t n_reads, int words_per_read, uint32_t *dst,
+                         int64_t dst_stride, int *error, hipStream_t stream)
+{
+    const int64_t total = n_reads * (int64_t)words_per_read;
+    if (total == 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(unpack_reads_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, codes, stride, code_words,
+                       lengths, uniform_len, n_reads, words_per_read, dst, dst_stride, error);
+}
+
+void launch_unpack_exceptions(const uint32_t *exc_reads, const uint32_t *exc_masks, int64_t n_exceptions,
+                              int code_words, int64_t first_read, int words_per_read, uint32_t *dst,
+                              int64_t dst_stride, hipStream_t stream)
+{
+    const int64_t total = n_exceptions * (int64_t)code_words;
+    if (total == 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(unpack_exceptions_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, exc_reads, exc_masks,
+                       n_exceptions, code_words, first_read, words_per_read, dst, dst_stride);
 }
 
 void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, int stats,

@@ -51,6 +51,7 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
     _LOG.info('Inferring transcript abundance')
     index = common.KMerIndex.load(index_path)
     _LOG.info('Mapping all reads')
+    _native.check(_native.hip().skm_pinned_set_device(device))     # (the readers' threads page-lock against THIS GPU)
     read_feeder = _feeder(fastq_paths, not single_ended, parse_threads, ranks.shard, save_readmap)
     map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
                                   readmap=readmap, debug=debug, device=device)
@@ -75,26 +76,33 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
 
 
 def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches):
-    """The native reader as run() uses it.  parse_threads None = choose: plain files are parsed by up
-    to 8 threads, into page-locked slabs when there is enough text (> 4 GiB) to pay for pinning
-    them, in batches of 2^18 units -- 2^20 above 16 GiB of text (the batching only paces the
-    hand-over: results do not depend on it; a batch is parsed by ONE thread, so the first ones
-    arrive after a whole batch's parsing time and small batches start the GPU sooner, while large
-    inputs amortise the per-batch launches better: 10 M pairs run at 113 M pairs/s end to end in
-    10 batches, 135 M in 40, 112 M in 80); 0 = the sequential engine in the reference's batches
-    of 65 536 (seekmer/common.py:17), which `-m` keeps so that readmap.txt is written batch by
-    batch as the reference writes it."""
+    """The native readers as run() uses them.
+
+    Plain files on one GPU: the one-pass reader (common.PackedReadFeeder) -- the text is parsed
+    straight to the mapper's 2-bit read codes by `parse_threads` workers (None = up to 16, the cores
+    this process may use less one) and drained into the mapper natively; a third of the bytes of the
+    ASCII batches cross PCIe.  Compressed inputs, several ranks (every rank takes every world-th
+    batch of the sample, which needs the line index of the two-pass reader) and `-m` (readmap.txt is
+    written batch by batch in the reference's batches of 65 536, seekmer/common.py:17) go through
+    common.NativeReadFeeder: plain files parsed by up to 8 threads, into page-locked slabs when
+    there is enough text (> 4 GiB) to pay for pinning them, in batches of 2^18 units (2^20 above
+    16 GiB of text); parse_threads 0 = its sequential engine."""
     import os
-    if parse_threads is None:
-        parse_threads = 0 if keep_reference_batches else min(8, os.cpu_count() or 1)
-    if parse_threads <= 0:
-        return common.NativeReadFeeder(fastq_paths, paired=paired, shard=shard)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     total = 0
     for path in fastq_paths:
         try:
             total += os.path.getsize(str(path))
         except OSError:
             pass
+    one_rank = shard is None or shard[1] <= 1
+    if one_rank and not keep_reference_batches and parse_threads != 0 and common.PackedReadFeeder.eligible(fastq_paths):
+        threads = parse_threads if parse_threads else max(1, min(16, cores - 1))
+        return common.PackedReadFeeder(fastq_paths, paired, threads=threads, pinned=total > (1 << 30))
+    if parse_threads is None:
+        parse_threads = 0 if keep_reference_batches else min(8, cores)
+    if parse_threads <= 0:
+        return common.NativeReadFeeder(fastq_paths, paired=paired, shard=shard)
     return common.NativeReadFeeder(fastq_paths, paired=paired, batch_units=1 << (20 if total > (16 << 30) else 18),
                                    threads=parse_threads, pinned=total > (4 << 30), shard=shard)
 

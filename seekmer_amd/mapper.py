@@ -17,7 +17,7 @@ import threading
 import numpy
 
 from . import _native
-from .common import ReadBatch
+from .common import PackedReadFeeder, PackedReads, ReadBatch
 
 __all__ = ('MAX_FRAGMENT_LENGTH', 'MapResult', 'ReadMapper', 'SummarizedResult',
            'map_reads', 'map_multiple_samples')
@@ -300,6 +300,26 @@ class ReadMapper:
             self.map_result._handle, batch.bases.ctypes.data,
             _native.ptr(batch.offsets, _native.c_i64p), batch.count, int(batch.paired), first_unit))
 
+    def push_packed(self, piece):
+        """Hand over reads that are already packed (common.PackedReads): copied to HBM now, mapped in
+        the background as soon as every stream of the sample covers a run of units."""
+        _native.check(_native.hip().skm_mapper_push_packed(
+            self.map_result._handle, ctypes.byref(piece.raw), int(piece.paired)))
+
+    def drain_packed(self, feeder):
+        """A PackedReadFeeder straight into the mapper without a Python step per piece
+        (skm_mapper_map_packed_source over skm_fastq_packed_next); returns the pieces pushed."""
+        reader = feeder.open()
+        try:
+            pieces = ctypes.c_int64()
+            _native.check(_native.hip().skm_mapper_map_packed_source(
+                self.map_result._handle, ctypes.cast(_native.host().skm_fastq_packed_next, ctypes.c_void_p),
+                reader.handle, int(feeder.paired), ctypes.byref(pieces)))
+        finally:
+            feeder.stats = reader.stats()
+            reader.close()
+        return pieces.value
+
     def last_batch(self, n_units):
         """(begin, end, anchor_entry, anchor_offset, counts, signed entries); the spans need a
         MapResult created with keep_spans=True."""
@@ -327,7 +347,16 @@ class ReadMapper:
 
     def __call__(self, reads_iterator):
         """Run the mapping loop (seekmer/_mapper.pyx:59-105)."""
+        if isinstance(reads_iterator, PackedReadFeeder) and self.map_result.readmap is None:
+            self.drain_packed(reads_iterator)
+            self.map_result.sync()
+            return
         for item in reads_iterator:
+            if isinstance(item, PackedReads):
+                if self.map_result.readmap is not None:
+                    raise ValueError('-m/--save-readmap needs the reads as text: use NativeReadFeeder')
+                self.push_packed(item)
+                continue
             if isinstance(item, ReadBatch):
                 batch = item
             else:
@@ -367,7 +396,8 @@ def map_reads(index, read_feeder, job_count=1, readmap=None, debug=False, device
     instead of being lost with its thread."""
     map_result = MapResult(index, readmap, device=device)
     try:
-        if debug or job_count <= 1:
+        if debug or job_count <= 1 or isinstance(read_feeder, PackedReadFeeder):
+            # (a packed feeder parses with its own threads and is drained natively: the GIL is not held)
             ReadMapper(index, map_result)(read_feeder)
         else:
             reads_queue = queue.Queue(job_count * 2)

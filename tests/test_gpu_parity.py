@@ -1177,3 +1177,141 @@ def test_async_batches_from_host_and_from_fastq(oracle, native_libs, tmp_path):
     for piece in pieces:
         rm.map_batch_async(piece)
     same(one)
+
+
+def _streams_of(common, bases, offsets, n_units, paired):
+    """The reads of a flat batch as one packed piece per stream (mate 1 reads, mate 2 reads)."""
+    mates = 2 if paired else 1
+    lengths = np.diff(offsets)
+    pieces = []
+    for s in range(mates):
+        sel = np.arange(s, mates * n_units, mates)
+        sub_offsets = np.zeros(n_units + 1, dtype=np.int64)
+        np.cumsum(lengths[sel], out=sub_offsets[1:])
+        sub = np.concatenate([bases[offsets[r]:offsets[r + 1]] for r in sel] + [np.zeros(1, np.uint8)])
+        pieces.append(common.PackedReads.from_ascii(sub, sub_offsets, stream=s, paired=paired))
+    return pieces
+
+
+def _cut(common, piece, borders):
+    """`piece` cut at `borders` (unit numbers) into pieces of their own."""
+    codes, lengths = piece.codes, piece.lengths
+    exc_reads, exc_masks = piece.exceptions
+    out = []
+    for lo, hi in zip(borders[:-1], borders[1:]):
+        sel = (exc_reads >= lo) & (exc_reads < hi)
+        out.append(common.PackedReads.from_arrays(piece.stream, lo, codes[lo:hi], lengths[lo:hi],
+                                                  exc_reads[sel] - lo, exc_masks[sel], paired=piece.paired))
+    return out
+
+
+@pytest.mark.parametrize('paired', [True, False])
+def test_packed_reads_give_the_same_tables(oracle, native_libs, chr21, chr21_oracle_index, paired, tmp_path):
+    """Reads packed on the host (2-bit code words + the bit planes of the reads with an N or a
+    lower-case letter) and pushed piece by piece -- streams cut at different places, pushed in any
+    order, interleaved with a stride, parsed from FASTQ text by the one-pass reader -- give the table
+    of the ASCII batch bit for bit (classes, order, counts, FLD, unaligned), which the oracle pins."""
+    from seekmer_amd import common, mapper
+    rng = np.random.default_rng(77)
+    reads = _adversarial_reads(chr21[1], rng, 6000, 100)
+    reads += _adversarial_reads(chr21[1], rng, 600, 150)           # ragged: two record sizes in one sample
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(reads)
+    mates = 2 if paired else 1
+    n_units = len(reads) // mates
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld)
+    whole = mapper.MapResult(index)
+    mapper.ReadMapper(index, whole).map_batch(common.ReadBatch(n_units, bases, offsets, paired))
+    _compare_tables(oracle, expected, fld, whole)
+    reference = whole.export()
+
+    def same(result):
+        for got, want in zip(result.export(), reference):
+            np.testing.assert_array_equal(got, want)
+        assert result.sizes() == whole.sizes()
+
+    streams = _streams_of(common, bases, offsets, n_units, paired)
+    assert sum(p.raw.n_exceptions for p in streams) > 500          # N / lower-case reads are there
+    # one piece per stream
+    one = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, one)
+    for piece in streams:
+        rm.push_packed(piece)
+    same(one)
+    # the streams cut at different places, the pieces pushed in a shuffled order
+    borders = [[0, 1, 700, 701, 2000, n_units], [0, 300, 1999, 2600, n_units]]
+    pieces = [p for s, piece in enumerate(streams) for p in _cut(common, piece, borders[s])]
+    for trial in range(3):
+        order = rng.permutation(len(pieces))
+        one.reset()
+        for k in order:
+            rm.push_packed(pieces[k])
+        same(one)
+    # mate 1 has reads without a mate at the end: dropped (zip(file1, file2))
+    if paired:
+        one.reset()
+        rm.push_packed(streams[0])
+        rm.push_packed(_cut(common, streams[1], [0, n_units - 100])[0])
+        assert one.sizes()[3] == n_units - 100
+        # a piece that overlaps what its stream holds replaces the reads from there on
+        one.reset()
+        wrong = _cut(common, streams[0], [0, 500, 3000])[1]
+        moved = common.PackedReads.from_arrays(1, 400, wrong.codes, wrong.lengths, *wrong.exceptions, paired=True)
+        first, rest = _cut(common, streams[1], [0, 400, n_units])
+        rm.push_packed(first)
+        rm.push_packed(moved)               # mate 2 reads [400, 2900) that are not the sample's ...
+        rm.push_packed(rest)                # ... replaced by the right ones before any mate 1 read arrives
+        rm.push_packed(streams[0])
+        same(one)
+        # both mates in one array, [unit][mate][words]: two pieces over it with a stride
+        cw = max(p.code_words for p in streams)
+        inter = np.zeros((n_units, 2, cw), dtype=np.uint64)
+        for s in range(2):
+            inter[:, s, :streams[s].code_words] = streams[s].codes
+        one.reset()
+        for s in range(2):
+            raw = native_libs.PackedReads()
+            raw.stream, raw.code_words, raw.first_read, raw.n_reads = s, cw, 0, n_units
+            raw.read_stride, raw.uniform_len = 2 * cw, -1
+            raw.codes = inter.ctypes.data + 8 * cw * s
+            lengths = np.ascontiguousarray(streams[s].lengths)
+            exc_reads, exc_masks = streams[s].exceptions
+            masks = np.zeros((exc_reads.size, cw), dtype=np.uint32)
+            masks[:, :streams[s].code_words] = exc_masks
+            raw.lengths = lengths.ctypes.data
+            raw.n_exceptions = exc_reads.size
+            raw.exception_reads = np.ascontiguousarray(exc_reads).ctypes.data
+            raw.exception_masks = masks.ctypes.data
+            rm.push_packed(common.PackedReads(raw, keep=(inter, lengths, exc_reads, masks), paired=True))
+        same(one)
+    # FASTQ text (N, lower case, CRLF line ends in one file) through the one-pass reader
+    files = [tmp_path / ('r_%d.fastq' % s) for s in range(mates)]
+    for s, path in enumerate(files):
+        with open(path, 'wb') as f:
+            end = b'\r\n' if s else b'\n'
+            for u in range(n_units):
+                read = reads[mates * u + s]
+                f.write(b'@u%d extra' % u + end + read + end + b'+' + end + b'@' * len(read) + end)
+    for threads, chunk, pinned in ((0, 0, False), (3, 50_000, True), (2, 1 << 20, False)):
+        feeder = common.PackedReadFeeder(files, paired, threads=threads, chunk_bytes=chunk, pinned=pinned)
+        text = mapper.map_reads(index, feeder, job_count=1)
+        same(text)
+        assert feeder.stats['units'] == n_units and feeder.stats['reparsed'] == 0
+        # ... and piece by piece through Python
+        one.reset()
+        rm(common.PackedReadFeeder(files, paired, threads=threads, chunk_bytes=chunk))
+        same(one)
+    # a read longer than its code words hold fails the sync, not the process
+    one.reset()
+    bad = common.PackedReads.from_arrays(0, 0, np.zeros((40000, 2), dtype=np.uint64), np.full(40000, 65, dtype=np.uint32),
+                                         paired=False)
+    bad.raw.uniform_len = -1
+    if not paired:
+        rm.push_packed(bad)
+        with pytest.raises(ValueError):
+            one.sync()
+        one.reset()
+        for piece in streams:
+            rm.push_packed(piece)
+        same(one)
