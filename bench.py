@@ -312,7 +312,7 @@ def main():
     ap.add_argument('--e2e-fastq-batches', type=int, default=40,
                     help='batches of the two-pass ASCII comparison leg')
     ap.add_argument('--parse-threads', type=int, default=14)
-    ap.add_argument('--e2e-chunk-mb', type=int, default=16, help='text range one parser thread takes at a time')
+    ap.add_argument('--e2e-chunk-mb', type=int, default=8, help='text range one parser thread takes at a time')
     ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
     args = ap.parse_args()
     shape = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100)}

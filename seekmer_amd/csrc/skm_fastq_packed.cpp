@@ -17,6 +17,7 @@
 #include "skm_pack_core.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <map>
@@ -138,7 +139,7 @@ struct skm_fastq_packed {
     std::vector<std::string> paths;
     bool paired = false, want_names = false;
     int n_threads = 0;
-    size_t chunk_bytes = 16u << 20;
+    size_t chunk_bytes = 8u << 20;
     alloc_fn al = malloc;
     free_fn fr = free;
     int variant = 0;
@@ -162,17 +163,24 @@ struct skm_fastq_packed {
     PackedOut *cur = nullptr;
     int64_t accepted = 0, reparsed = 0, n_reads = 0, n_exceptions = 0;
     bool failed = false;
+    const bool trace = getenv("SKM_FASTQ_TRACE") != nullptr;      // tuning aid: per-piece timings on stderr
 
     Result parse(const Item &it)
     {
         Result r;
         const Mapped &f = files[(size_t)it.file];
+        const auto t0 = std::chrono::steady_clock::now();
         r.out = take_piece(al, fr);
         if (!r.out) return r;
+        const size_t before = r.out->bytes();
         r.out->start(cw_hint.load(std::memory_order_relaxed), want_names && it.stream == 0);
         if (it.a == 0) { r.has_start = true; r.start = 0; }
         else r.has_start = guess_start(f.p, f.n, it.a, it.b, &r.start);
         if (r.has_start) r.end = walk(f.p, f.n, r.start, it.b, *r.out);
+        if (trace)
+            fprintf(stderr, "[skm_fastq_packed] file %d [%zu, %zu): %lld reads in %.2f ms (arrays %zu -> %zu bytes)\n", it.file,
+                    it.a, it.b, (long long)r.out->n_reads,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), before, r.out->bytes());
         return r;
     }
 
@@ -183,7 +191,7 @@ struct skm_fastq_packed {
             {
                 std::unique_lock<std::mutex> hold(pm);
                 pcv.wait(hold, [&] {
-                    return stop || next_claim >= items.size() || next_claim < next_deliver + 2 * (size_t)n_threads + 2;
+                    return stop || next_claim >= items.size() || next_claim < next_deliver + (size_t)n_threads + 4;
                 });
                 if (stop || next_claim >= items.size()) return;
                 k = next_claim++;

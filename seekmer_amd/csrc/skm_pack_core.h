@@ -383,6 +383,14 @@ inline size_t walk_impl(const char *text, size_t n, size_t start, size_t stop, P
         if (plus_end >= end) { at = n; break; }
         const char *qual_end = find_newline(plus_end + 1, end);
         at = qual_end >= end ? n : (size_t)(qual_end - text) + 1;
+        if (out.n_reads == 1 && at > start) {
+            // size the arrays for the whole range from the first record (growing a page-locked array
+            // means locking a new one): records of this size, and some slack
+            const size_t span = (stop < n ? stop : n) - start, record = at - start;
+            const size_t expect = span / record + span / record / 16 + 64;
+            out.codes.reserve(expect * (size_t)out.cw);
+            out.lengths.reserve(expect);
+        }
     }
     return at;
 }
