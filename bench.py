@@ -16,9 +16,12 @@ seeded stand-in).  Inputs are resident in HBM when the timed region starts.
 
 For N > 1 (launched by torch.distributed.run, one rank per GPU) reads shard
 across ranks with no collective while mapping and one RCCL all-reduce of
-f64[T] per EM step; rank 0 prints ONE JSON line.  At N = 1 and --config 1 the
-line also carries `e2e`: the same workload timed from host arrays (PCIe
-inclusive) and from FASTQ text -- neither is `value`.
+f64[T] per EM step (--config 4: the merged table on every rank, the replicates
+shared out, no collective while they run); rank 0 prints ONE JSON line.  The
+default run (N = 1, --config 1) also carries `e2e`: the same workload timed
+from host arrays (PCIe inclusive) and from FASTQ text -- neither is `value` --
+and `other_configs`: a few timed steps of configs[3] and configs[4] on the
+same index.
 """
 import argparse
 import ctypes
@@ -35,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_SUMMARY = os.path.join('profiles', 'r02_pmc_map.json')     # rocprofv3 --pmc passes of the map kernel
+PMC_SUMMARY = os.path.join('profiles', 'r03_pmc_map.json')     # rocprofv3 --pmc passes of the map kernel
 
 
 def log(*a):
@@ -294,99 +297,32 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', type=int, default=1, choices=(1, 3, 4), help='BASELINE.json configs[] index')
-    ap.add_argument('--genes', type=int, default=20000, help='synthetic genes (20000 -> ~190k tx)')
-    ap.add_argument('--pairs', type=int, default=0, help='units per GPU per step (default: the config\'s size)')
-    ap.add_argument('--read-len', type=int, default=0)
-    ap.add_argument('--bootstraps', type=int, default=-1, help='-b N inside the step (default: 100 for --config 4)')
-    ap.add_argument('--seed', type=int, default=1)
-    ap.add_argument('--cpu-sample', type=int, default=1_000_000)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-e2e', action='store_true')
-    ap.add_argument('--e2e-batches', type=int, default=10, help='pieces of the host-array leg')
-    ap.add_argument('--e2e-fastq-batches', type=int, default=40,
-                    help='batches of the two-pass ASCII comparison leg')
-    ap.add_argument('--parse-threads', type=int, default=14)
-    ap.add_argument('--e2e-chunk-mb', type=int, default=8, help='text range one parser thread takes at a time')
-    ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
-    args = ap.parse_args()
-    shape = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100)}
-    n_units, read_len, paired, bootstraps = shape[args.config]
-    n_units = args.pairs or n_units
-    args.read_len = read_len = args.read_len or read_len
-    bootstraps = bootstraps if args.bootstraps < 0 else args.bootstraps
+SHAPES = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100)}
+
+
+def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=-1, with_cpu=True, with_e2e=False):
+    """One configuration on the index that is already in HBM: `warmup` untimed steps, EXACTLY `steps`
+    timed ones between barrier + device synchronisation, the roofline of the map kernel from its own
+    HIP-event times, and (rank 0) the JSON line's dict."""
+    from seekmer_amd import infer, mapper, parallel, synth
+    hip, _native, index, device = ctx['hip'], ctx['native'], ctx['index'], ctx['device']
+    rank, world, dist, comm = ctx['rank'], ctx['world'], ctx['dist'], ctx['comm']
+    pool, tx_offsets, n_tx = ctx['pool'], ctx['tx_offsets'], ctx['n_tx']
+    shape = SHAPES[config]
+    n_units = n_units or shape[0]
+    read_len = read_len or shape[1]
+    paired = shape[2]
+    bootstraps = shape[3] if bootstraps < 0 else bootstraps
     unit_name = 'pairs' if paired else 'reads'
-    if bootstraps and int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        raise SystemExit('configs[4] (-b N) is a single-GPU configuration: bootstraps resample the merged table')
+    ranks = parallel.Ranks(rank, world, ctx['local_rank'], dist)
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`' % (args.gpus, args.gpus))
-            sys.exit(2)
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)   # rendezvous / barrier only
-
-    from seekmer_amd import _native, common, index_builder, infer, mapper, parallel, synth
-    hip = _native.hip()
-    device = local_rank
-    if os.environ.get('SKM_BENCH_ONE_DEVICE') == '1':      # rehearsal of the N > 1 path on a 1-GPU box
-        device = 0
-    if _native.device_count() <= device:
-        raise SystemExit('no GPU %d visible: the benchmark has no CPU path' % device)
-
-    # ---------------- setup (untimed): transcriptome, index, reads -> HBM
-    t0 = time.perf_counter()
-    ids, pool, tx_offsets = synth.transcriptome(args.seed, args.genes)
-    # one rank builds the index, the others map the container it wrote (2.2 GB, memory-mapped)
-    index = parallel.shared_index(lambda: index_builder.build_pooled(ids, pool, tx_offsets), rank, world,
-                                  barrier=(dist.barrier if dist is not None else None),
-                                  cache=args.index_cache or None)
-    n_tx = len(ids)
-    log('rank %d: %d transcripts, %d k-mer slots, index ready in %.1fs'
-        % (rank, n_tx, index.kmers.size, time.perf_counter() - t0))
     bases, offsets = synth.reads(args.seed, pool, tx_offsets, rank * n_units, n_units, read_len, paired)
-    index.device_handle(device)
     d_bases, d_offsets = ctypes.c_void_p(), ctypes.c_void_p()
     _native.check(hip.skm_device_malloc(device, bases.size, ctypes.byref(d_bases)))
     _native.check(hip.skm_device_malloc(device, offsets.size * 8, ctypes.byref(d_offsets)))
     _native.check(hip.skm_device_upload(device, d_bases, bases.ctypes.data, bases.size))
     _native.check(hip.skm_device_upload(device, d_offsets, offsets.ctypes.data, offsets.size * 8))
     result = mapper.MapResult(index, device=device)
-    comm_id = None
-    force_comm = world == 1 and os.environ.get('SKM_FORCE_COMM') == '1'   # 1-rank RCCL rehearsal
-    if force_comm:
-        raw = ctypes.create_string_buffer(128)
-        _native.check(hip.skm_comm_unique_id(raw))
-        comm_id = raw.raw
-    if world > 1:
-        import torch
-        buf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = ctypes.create_string_buffer(128)
-            _native.check(hip.skm_comm_unique_id(raw))
-            buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-        dist.broadcast(buf, 0)
-        comm_id = bytes(buf.numpy().tobytes())
-    comm = ctypes.c_void_p()
-    if comm_id is not None:                # one communicator per process, reused by every step
-        comm = parallel.create_comm(device, comm_id, rank, world)     # (RCCL's banner goes to stderr)
-    rccl_ranks = 0
-    if comm:
-        n = ctypes.c_int(0)
-        _native.check(hip.skm_comm_count(comm, ctypes.byref(n)))
-        rccl_ranks = n.value
 
     state = {'boot_s': 0.0, 'boot_iters': 0}
     stage = {}
@@ -400,6 +336,14 @@ def main():
             stage[name] = stage.get(name, 0.0) + time.perf_counter() - t0
         return time.perf_counter()
 
+    def quantify_ranks(map_result):
+        # fragment lengths (RCCL all-reduce over the ranks) -> effective lengths -> start vector -> EM
+        # -> TPM: one native call on the resident class table
+        tpm, iters, eff = infer.quantify_resident(map_result, comm=comm if comm else None, return_iters=True,
+                                                  return_effective_lengths=True)
+        state['iters'], state['eff'] = iters, eff
+        return tpm
+
     def step():
         t = time.perf_counter()
         result.reset()
@@ -407,41 +351,49 @@ def main():
         result.map_resident(d_bases, d_offsets, n_units, paired, read_len)
         t = mark('map_batch', t)
         before = result.timing()
-        # fragment lengths (RCCL all-reduce over the ranks) -> effective lengths -> start
-        # vector -> EM -> TPM: one native call on the resident class table
-        tpm, iters, eff = infer.quantify_resident(result, comm=comm if comm else None, return_iters=True,
-                                                  return_effective_lengths=True)
+        tpm = quantify_ranks(result)
         t = mark('quantify', t)
         after = result.timing()
         state['em'] = {'em_ns': after['em_ns'] - before['em_ns'],
                        'iterations': after['em_iterations'] - before['em_iterations']}
         state['tpm'] = tpm
-        state['iters'] = iters
-        if bootstraps:                     # `-b N` (seekmer/infer.py:79-82): resample + EM from the main estimate
-            t_b = time.perf_counter()
+        if not bootstraps:
+            return
+        # `-b N` (seekmer/infer.py:79-82): resample the table of the whole sample + EM from the main estimate
+        t_b = time.perf_counter()
+        if world == 1:
             quant = infer._QuantHandle.from_map_result(result, n_tx)
-            if comm:
+            if comm:                       # (1-rank RCCL rehearsal: every replicate's steps all-reduced)
                 _native.check(hip.skm_quant_set_comm(quant.handle, comm))
             x0 = tpm / tpm.sum()
-            out, _, it = quant.bootstrap(bootstraps, args.seed, x0, eff, tpm=True)    # TPM vectors, as run() keeps them
+            out, _, it = quant.bootstrap(bootstraps, args.seed, x0, state['eff'], tpm=True)   # TPM vectors, as run() keeps them
             state['boot_tpm'] = out
             quant.close()
-            state['boot_s'] += time.perf_counter() - t_b
             state['boot_iters'] += int(it.sum())
-            mark('bootstrap', t)
+        else:
+            # several ranks: the tables go to rank 0 and are merged on its GPU, the merged table to
+            # every rank, rank r runs replicates r, r + G, ... (no collective), rank 0 gathers them
+            tables = ranks.gather_arrays_to_root(parallel.rank_table(result) if rank else {})
+            summarized = None
+            if rank == 0:
+                parallel.merge_into(result, tables[1:])
+                summarized = result.summarize()
+            state['boot_tpm'] = infer.bootstrap_ranks(summarized, tpm, bootstraps, ranks, seed=args.seed, device=device)
+        state['boot_s'] += time.perf_counter() - t_b
+        mark('bootstrap', t)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         _native.check(hip.skm_device_synchronize(device))
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     state['boot_s'], state['boot_iters'] = 0.0, 0
     t_before = result.timing()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -462,7 +414,7 @@ def main():
             raise SystemExit('EM step counts differ between ranks: %s' % em_steps_check)
     t_after = result.timing()
     if profile_stages and rank == 0:
-        log('stage ms per step: ' + ', '.join('%s %.2f' % (k, 1e3 * v / (args.steps + args.warmup))
+        log('stage ms per step: ' + ', '.join('%s %.2f' % (k, 1e3 * v / (steps + warmup))
                                               for k, v in stage.items()))
 
     # ---------------- roofline of the dominant kernel
@@ -489,7 +441,7 @@ def main():
     try:
         with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             pmc = json.load(f)
-        if args.config == 1 and args.genes == 20000 and n_units == 10_000_000 and read_len == 100:
+        if config == 1 and args.genes == 20000 and n_units == 10_000_000 and read_len == 100:
             traffic = pmc['derived']['hbm_traffic_bytes']
             traffic_source = 'quoted from %s (rocprofv3 --pmc passes of this build on this workload), ' \
                              'not measured by this run' % PMC_SUMMARY
@@ -497,16 +449,17 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    line = None
     if rank == 0:
-        total_units = world * n_units * args.steps
+        total_units = world * n_units * steps
         line = {
             'metric': 'paired reads/sec mapped+quantified' if paired else 'reads/sec mapped+quantified (single-end)',
             'value': total_units / elapsed,
             'unit': '%s/s' % unit_name,
             'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': 1000.0 * elapsed / args.steps,
+            'steps': steps,
+            'warmup': warmup,
+            'ms_per_step': 1000.0 * elapsed / steps,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -515,7 +468,7 @@ def main():
             'config': {
                 'workload': 'configs[%d]: synthetic ~190k-tx index (stand-in for ENSEMBL GRCh38 cDNA), '
                             '%d %s synthetic %s per GPU, map+classes+EM to the reference stop rule%s'
-                            % (args.config, n_units, ('2x%dbp' if paired else '%dbp single-end') % read_len,
+                            % (config, n_units, ('2x%dbp' if paired else '%dbp single-end') % read_len,
                                unit_name, ' + %d bootstraps (-b)' % bootstraps if bootstraps else ''),
                 'transcripts': n_tx, 'kmer_slots': int(index.kmers.size),
                 'units_per_gpu': n_units, 'read_len': read_len, 'paired': paired,
@@ -524,8 +477,9 @@ def main():
                 'em_iters_per_s': state['em']['iterations'] / (state['em']['em_ns'] * 1e-9),
                 'em_bytes_per_step': em_bytes,
                 'em_algorithmic_GBps': em_bytes * state['em']['iterations'] / max(state['em']['em_ns'], 1.0),
-                'parallelism': 'reads sharded x%d, RCCL all-reduce f64[T] per EM step' % world,
-                'rccl_ranks': rccl_ranks,
+                'parallelism': 'reads sharded x%d, RCCL all-reduce f64[T] per EM step%s'
+                               % (world, '; bootstraps shared out over the ranks' if bootstraps and world > 1 else ''),
+                'rccl_ranks': ctx['rccl_ranks'],
                 'phase_ms': {'pack': pack_ns * 1e-6, 'map': map_ns * 1e-6, 'classes': class_ns * 1e-6,
                              'em': state['em']['em_ns'] * 1e-6},
             },
@@ -547,15 +501,129 @@ def main():
             line['config']['em_steps_over_ranks'] = em_steps_check
         if bootstraps:
             line['config']['bootstraps'] = bootstraps
-            line['config']['bootstraps_per_s'] = bootstraps * args.steps / state['boot_s']
-            line['config']['bootstrap_em_steps'] = state['boot_iters'] // args.steps
-            line['config']['phase_ms']['bootstraps'] = 1e3 * state['boot_s'] / args.steps
-        if not args.no_cpu_baseline and world == 1:
+            line['config']['bootstraps_per_s'] = bootstraps * steps / state['boot_s']
+            if world == 1:
+                line['config']['bootstrap_em_steps'] = state['boot_iters'] // steps
+            line['config']['phase_ms']['bootstraps'] = 1e3 * state['boot_s'] / steps
+        if with_cpu and world == 1:
             line['cpu_baseline'] = cpu_baseline(index, pool, tx_offsets, args.seed, read_len,
                                                 min(args.cpu_sample, n_units), paired,
                                                 bootstraps=min(bootstraps, 3))
-        if world == 1 and args.config == 1 and not args.no_e2e:
+        if with_e2e and world == 1:
+            del result
+            _native.check(hip.skm_device_free(device, d_bases))
+            _native.check(hip.skm_device_free(device, d_offsets))
+            d_bases = d_offsets = None
             line['e2e'] = e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx)
+    if d_bases:
+        del result
+        _native.check(hip.skm_device_free(device, d_bases))
+        _native.check(hip.skm_device_free(device, d_offsets))
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', type=int, default=1, choices=(1, 3, 4), help='BASELINE.json configs[] index')
+    ap.add_argument('--genes', type=int, default=20000, help='synthetic genes (20000 -> ~190k tx)')
+    ap.add_argument('--pairs', type=int, default=0, help='units per GPU per step (default: the config\'s size)')
+    ap.add_argument('--read-len', type=int, default=0)
+    ap.add_argument('--bootstraps', type=int, default=-1, help='-b N inside the step (default: 100 for --config 4)')
+    ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--cpu-sample', type=int, default=1_000_000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short legs of configs[3] and configs[4] that follow a default run')
+    ap.add_argument('--other-steps', type=int, default=3)
+    ap.add_argument('--e2e-batches', type=int, default=10, help='pieces per stream of the host-array leg')
+    ap.add_argument('--e2e-fastq-batches', type=int, default=40,
+                    help='batches of the two-pass ASCII comparison leg')
+    ap.add_argument('--parse-threads', type=int, default=14)
+    ap.add_argument('--e2e-chunk-mb', type=int, default=8, help='text range one parser thread takes at a time')
+    ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
+    args = ap.parse_args()
+    args.read_len = args.read_len or SHAPES[args.config][1]
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`' % (args.gpus, args.gpus))
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)   # rendezvous / barrier / host-side exchanges
+
+    from seekmer_amd import _native, index_builder, parallel, synth
+    hip = _native.hip()
+    device = local_rank
+    if os.environ.get('SKM_BENCH_ONE_DEVICE') == '1':      # rehearsal of the N > 1 path on a 1-GPU box
+        device = 0
+    if _native.device_count() <= device:
+        raise SystemExit('no GPU %d visible: the benchmark has no CPU path' % device)
+
+    # ---------------- setup (untimed): transcriptome, index -> HBM, communicator
+    t0 = time.perf_counter()
+    ids, pool, tx_offsets = synth.transcriptome(args.seed, args.genes)
+    # one rank builds the index, the others map the container it wrote (2.2 GB, memory-mapped)
+    index = parallel.shared_index(lambda: index_builder.build_pooled(ids, pool, tx_offsets), rank, world,
+                                  barrier=(dist.barrier if dist is not None else None),
+                                  cache=args.index_cache or None)
+    n_tx = len(ids)
+    log('rank %d: %d transcripts, %d k-mer slots, index ready in %.1fs'
+        % (rank, n_tx, index.kmers.size, time.perf_counter() - t0))
+    index.device_handle(device)
+    comm_id = None
+    force_comm = world == 1 and os.environ.get('SKM_FORCE_COMM') == '1'   # 1-rank RCCL rehearsal
+    if force_comm:
+        raw = ctypes.create_string_buffer(128)
+        _native.check(hip.skm_comm_unique_id(raw))
+        comm_id = raw.raw
+    if world > 1:
+        comm_id = parallel.broadcast_comm_id(dist, rank)
+    comm = ctypes.c_void_p()
+    if comm_id is not None:                # one communicator per process, reused by every step
+        comm = parallel.create_comm(device, comm_id, rank, world)     # (RCCL's banner goes to stderr)
+    rccl_ranks = 0
+    if comm:
+        n = ctypes.c_int(0)
+        _native.check(hip.skm_comm_count(comm, ctypes.byref(n)))
+        rccl_ranks = n.value
+    ctx = {'hip': hip, 'native': _native, 'index': index, 'device': device, 'rank': rank, 'world': world,
+           'local_rank': local_rank, 'dist': dist, 'comm': comm, 'rccl_ranks': rccl_ranks, 'pool': pool,
+           'tx_offsets': tx_offsets, 'n_tx': n_tx}
+
+    default_run = world == 1 and args.config == 1 and not args.pairs
+    line = measure(args, ctx, args.config, args.steps, args.warmup, n_units=args.pairs, read_len=args.read_len,
+                   bootstraps=args.bootstraps, with_cpu=not args.no_cpu_baseline,
+                   with_e2e=default_run and not args.no_e2e)
+    if default_run and not args.no_other_configs:
+        # the other single-GPU configurations of BASELINE.json, a few steps each on the same index
+        # (parity at these sizes: tests/test_gpu_parity.py::test_baseline_config{3,4}_properties)
+        line['other_configs'] = {}
+        for other in (3, 4):
+            t0 = time.perf_counter()
+            sub = measure(args, ctx, other, args.other_steps, 1, with_cpu=False)
+            log('configs[%d]: %.1f M %s, %.1f ms per step (%.0fs with set-up)'
+                % (other, sub['value'] / 1e6, sub['unit'], sub['ms_per_step'], time.perf_counter() - t0))
+            keep = {k: sub[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step')}
+            keep['workload'] = sub['config']['workload']
+            keep['phase_ms'] = sub['config']['phase_ms']
+            for k in ('classes', 'em_iterations', 'em_iters_per_s', 'bootstraps', 'bootstraps_per_s'):
+                if k in sub['config']:
+                    keep[k] = sub['config'][k]
+            keep['roofline'] = {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                'algorithmic_bytes_per_launch', 'launch_ms')}
+            line['other_configs']['configs[%d]' % other] = keep
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if comm:
         _native.check(hip.skm_comm_destroy(comm))

@@ -262,6 +262,15 @@ int skm_quant_bootstrap_tpm(skm_quant *quant, int64_t n_boot, uint64_t seed,
                             const double *x0, const double *l, double rel_tol,
                             double x_floor, int64_t max_iters, double *out,
                             int64_t *iters_out);
+/* One rank's share of the `-b N` loop: the n_boot replicates numbered first,
+ * first + step, first + 2 step, ... of the run; out[n_boot][n_tx] as skm_quant_bootstrap_tpm.  A
+ * replicate's draw depends on (seed, its number) alone, so ranks r = 0 .. G-1 calling with
+ * (first = r, step = G) on the same merged table produce, together, exactly the replicates of
+ * skm_quant_bootstrap_tpm(N) -- no collective, one gather of the results. */
+int skm_quant_bootstrap_share_tpm(skm_quant *quant, int64_t n_boot, int64_t first, int64_t step,
+                                  uint64_t seed, const double *x0, const double *l, double rel_tol,
+                                  double x_floor, int64_t max_iters, double *out,
+                                  int64_t *iters_out);
 /* EM with externally supplied class counts (parity of the bootstrap EM leg). */
 int skm_quant_set_counts(skm_quant *quant, const double *class_counts);
 /* timing[0]=EM kernel ns total [1]=iterations [2]=launches */

@@ -99,6 +99,9 @@ HIP_SYMBOLS = {
     'skm_quant_bootstrap_tpm': (ctypes.c_int, [ctypes.c_void_p, c_i64, ctypes.c_uint64, c_f64p,
                                                c_f64p, ctypes.c_double, ctypes.c_double, c_i64,
                                                c_f64p, c_i64p]),
+    'skm_quant_bootstrap_share_tpm': (ctypes.c_int, [ctypes.c_void_p, c_i64, c_i64, c_i64, ctypes.c_uint64, c_f64p,
+                                                     c_f64p, ctypes.c_double, ctypes.c_double, c_i64,
+                                                     c_f64p, c_i64p]),
     'skm_quant_set_counts': (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     'skm_quant_timing': (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
     'skm_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),

@@ -2029,13 +2029,23 @@ extern "C" int skm_quant_set_counts(skm_quant *q, const double *class_counts)
 }
 
 namespace {
+// Replicate b of the call (b = 0 .. n_boot - 1) is replicate number rep_first + b * rep_step of the
+// `-b N` run: its draw depends on (seed, that number) alone, so a rank's share of the replicates
+// gives the same results as the one-GPU loop, replicate by replicate.
 int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0,
                    const double *l, double rel_tol, double x_floor, int64_t max_iters,
-                   double *out, int64_t *counts_out, int64_t *iters_out, bool tpm)
+                   double *out, int64_t *counts_out, int64_t *iters_out, bool tpm,
+                   int64_t rep_first = 0, int64_t rep_step = 1)
 {
-    if (!q || !x0 || !l || !out || n_boot < 0) return fail(SKM_ERR_ARG, "bad argument");
+    if (!q || !x0 || !l || !out || n_boot < 0 || rep_first < 0 || rep_step < 1) return fail(SKM_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(q->mu);
     SKM_TRY(set_device(q->device));
+    // (seekmer/infer.py:108-111 resamples the table of the WHOLE sample: a handle that holds one
+    // rank's share of the classes -- a communicator of several ranks attached -- cannot)
+    if (q->comm && q->world > 1)
+        return fail(SKM_ERR_STATE, "bootstraps resample the merged class table: detach the communicator "
+                                   "(skm_quant_set_comm(quant, NULL)) and give every rank the merged table");
+    auto number = [&](int64_t b) { return (uint64_t)(rep_first + b * rep_step); };
     const int64_t C = q->n_classes;
     if (C == 0) return fail(SKM_ERR_STATE, "no classes to resample");
     // integer cumulative counts of the observed table
@@ -2069,7 +2079,7 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     // One replicate the careful way (host-checked chunks of the single-problem EM): draw, EM from
     // x_start, result to `dst` (HBM).
     auto replicate_checked = [&](int64_t b, int64_t *it_out, double *dst) -> int {
-        if (!launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)b, q->tile_total.p, q->cls_count.p, 1, q->stream))
+        if (!launch_multinomial(q->cum.p, C, n_draws, seed, number(b), q->tile_total.p, q->cls_count.p, 1, q->stream))
             return fail(SKM_ERR_STATE, "class table too large to resample (%lld classes)", (long long)C);
         HIP_TRY(hipGetLastError());
         if (counts_out) {
@@ -2155,7 +2165,7 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
         int64_t next = w0, k = 0;                                // next replicate to start; steps queued so far
         unsigned int idle = 0;
         auto start = [&](int r) -> int {                         // replicate `next` into place r, from step k on
-            if (!launch_multinomial(q->cum.p, C, n_draws, seed, (uint64_t)next, q->tile_total.p,
+            if (!launch_multinomial(q->cum.p, C, n_draws, seed, number(next), q->tile_total.p,
                                     w.cls_count.p + r, EM_BATCH, q->stream))
                 return fail(SKM_ERR_STATE, "class table too large to resample (%lld classes)", (long long)C);
             launch_em_batch_place(q->x_start.p, T, r, p.x[k & 1], p.part_max, p.part_flags, q->stream);
@@ -2236,6 +2246,13 @@ extern "C" int skm_quant_bootstrap_tpm(skm_quant *q, int64_t n_boot, uint64_t se
                                        double *out, int64_t *iters_out)
 {
     return bootstrap_impl(q, n_boot, seed, x0, l, rel_tol, x_floor, max_iters, out, nullptr, iters_out, true);
+}
+
+extern "C" int skm_quant_bootstrap_share_tpm(skm_quant *q, int64_t n_boot, int64_t first, int64_t step, uint64_t seed,
+                                             const double *x0, const double *l, double rel_tol, double x_floor,
+                                             int64_t max_iters, double *out, int64_t *iters_out)
+{
+    return bootstrap_impl(q, n_boot, seed, x0, l, rel_tol, x_floor, max_iters, out, nullptr, iters_out, true, first, step);
 }
 
 extern "C" int skm_quant_timing(skm_quant *q, double timing[4])

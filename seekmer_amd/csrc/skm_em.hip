@@ -423,12 +423,12 @@ multinomial_classes_kernel(const unsigned long long *__restrict__ cum, int64_t n
         __syncthreads();
         const uint32_t reject_below = (uint32_t)(0u - mass) % mass;
         MnStream rng(seed, stream_id, 1 + blockIdx.x);
-        const unsigned int n_pairs = (draws + 1) >> 1;
+        const unsigned int n_pairs = (unsigned int)(((unsigned long long)draws + 1) >> 1);    // (draws may be 2^32 - 1)
         for (unsigned int p = threadIdx.x; p < n_pairs; p += blockDim.x) {
             const uint64_t w = rng.words(p);
             const uint32_t r0 = mn_bounded((uint32_t)(w >> 32), mass, reject_below, rng, p, 0u);
             atomicAdd(&count[mn_find(local_cum, guide, shift, r0)], 1u);
-            if (2 * p + 1 < draws) {
+            if (2ull * p + 1 < draws) {
                 const uint32_t r1 = mn_bounded((uint32_t)w, mass, reject_below, rng, p, 1u);
                 atomicAdd(&count[mn_find(local_cum, guide, shift, r1)], 1u);
             }

@@ -17,7 +17,7 @@ from . import _native
 from . import common
 from . import mapper
 
-__all__ = ['run', 'quantify', 'quantify_resident', 'em', 'output_results', 'bootstrap_quantify']
+__all__ = ['run', 'quantify', 'quantify_resident', 'em', 'output_results', 'bootstrap_quantify', 'bootstrap_ranks']
 
 _LOG = logging.getLogger(__name__)
 
@@ -30,13 +30,26 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
     """The entrypoint of the inference module (seekmer/infer.py:27-85).
 
     Started as one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m
-    seekmer_amd infer ...`) the sample is shared out batch by batch: every rank maps its
-    batches on its own GPU against its own replica of the index, the EM runs over the rank-local
-    class tables with one RCCL all-reduce per step, and rank 0 -- after merging the ranks' tables
-    on its GPU -- writes the outputs of the whole sample."""
+    seekmer_amd infer ...`; experimental: no multi-GPU node has run it yet) the sample is shared out
+    batch by batch: every rank maps its batches on its own GPU against its own replica of the
+    index, the EM runs over the rank-local class tables with one RCCL all-reduce per step, rank 0
+    merges the ranks' tables on its GPU, the `-b N` replicates are shared out over the ranks again
+    (the merged table on every rank, no collective while they run), and rank 0 writes the outputs
+    of the whole sample.  A rank that fails ends the job (parallel.Ranks.fail)."""
     from . import parallel
     start_time = datetime.datetime.utcnow()
     ranks = parallel.Ranks.from_env()
+    try:
+        _run(ranks, start_time, index_path, output_path, fastq_paths, job_count, save_readmap, single_ended,
+             bootstrap, debug, device, seed, parse_threads)
+    except BaseException as error:          # noqa: B902 -- one rank: re-raised as it is
+        ranks.fail(error)
+    ranks.close()
+
+
+def _run(ranks, start_time, index_path, output_path, fastq_paths, job_count, save_readmap, single_ended,
+         bootstrap, debug, device, seed, parse_threads):
+    from . import parallel
     if ranks.world > 1:
         device = ranks.local_rank
         if save_readmap:
@@ -56,6 +69,8 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
     map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
                                   readmap=readmap, debug=debug, device=device)
     _LOG.info('Mapped all reads')
+    if bootstrap > 0:
+        _check_resample_limit(map_result, ranks)
     comm = parallel.make_comm(ranks, device)
     try:
         summarized_results, main_result = finish(map_result, ranks,
@@ -67,12 +82,26 @@ def run(index_path, output_path, fastq_paths, job_count, save_readmap,
         _LOG.info('Aligned %d reads (%.2f%%)', summarized_results.aligned,
                   100.0 * summarized_results.aligned / summarized_results.total)
         _LOG.info('Quantified transcripts')
-        bootstrapped_results = bootstrap_quantify(summarized_results, main_result, bootstrap,
-                                                  seed=seed)
+    bootstrapped_results = bootstrap_ranks(summarized_results, main_result, bootstrap, ranks, seed=seed, device=device)
+    if ranks.rank == 0:
         output_results(output_path, index, start_time, summarized_results,
                        main_result, bootstrapped_results)
         _LOG.info('Wrote results to %s', output_path)
-    ranks.close()
+
+
+RESAMPLE_LIMIT = 2 ** 32 - 1        # units one multinomial draw can resample (skm_quant_bootstrap*)
+
+
+def _check_resample_limit(map_result, ranks):
+    """`-b N` draws n = class_count.sum() units per replicate (seekmer/infer.py:108-111); the device
+    draw counts them in 32 bits.  Said now, before the EM, not after it."""
+    _, _, unaligned, total = map_result.sizes()
+    aligned = total - unaligned
+    if ranks.world > 1:
+        aligned = sum(ranks.gather_to_root(aligned) or [0])
+    if ranks.rank == 0 and aligned > RESAMPLE_LIMIT:
+        raise ValueError('-b/--bootstrap resamples at most %d aligned units per replicate; this sample has %d'
+                         % (RESAMPLE_LIMIT, aligned))
 
 
 def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches):
@@ -120,7 +149,7 @@ def finish(map_result, ranks, quantify_ranks):
         return summarized, quantify(summarized)
     _LOG.info('Quantifying transcripts')
     tpm = quantify_ranks(map_result)
-    tables = ranks.gather_to_root(parallel.rank_table(map_result) if ranks.rank else None)
+    tables = ranks.gather_arrays_to_root(parallel.rank_table(map_result) if ranks.rank else {})
     if ranks.rank != 0:
         return None, tpm
     parallel.merge_into(map_result, tables[1:])
@@ -308,6 +337,65 @@ def bootstrap_quantify(results, x0, n_boot, seed=None):
         if owned:
             quant.close()
     return list(out)
+
+
+def _bootstrap_share(table, x0, first, step, count, seed, device=0):
+    """Replicates first, first + step, ... (`count` of them) of the `-b N` loop on this process's GPU:
+    TPM vectors [count, T] (skm_quant_bootstrap_share_tpm)."""
+    n_tx = table['effective_lengths'].size
+    out = numpy.zeros((count, n_tx), dtype='f8')
+    if count == 0:
+        return out
+    quant = _QuantHandle.from_csr(n_tx, table['class_offsets'], table['class_targets'], table['class_count'], device)
+    try:
+        x = numpy.array(x0, dtype='f8')
+        x /= x.sum()
+        length = numpy.ascontiguousarray(table['effective_lengths'], dtype='f8')
+        iters = numpy.zeros(count, dtype=numpy.int64)
+        _native.check(_native.hip().skm_quant_bootstrap_share_tpm(
+            quant.handle, count, first, step, seed, _native.ptr(x, _native.c_f64p), _native.ptr(length, _native.c_f64p),
+            REL_TOL, X_FLOOR, 0, _native.ptr(out, _native.c_f64p), _native.ptr(iters, _native.c_i64p)))
+    finally:
+        quant.close()
+    return out
+
+
+def bootstrap_ranks(results, x0, n_boot, ranks, seed=None, device=0, share=_bootstrap_share):
+    """The `-b N` loop of run() (seekmer/infer.py:79-82) over the ranks: rank 0
+    (the only one that holds `results`, the summary of the merged table, and `x0`, the main estimate)
+    shares the merged table; rank r runs the replicates r, r + G, ... on its GPU with no collective;
+    the TPM vectors are gathered on rank 0 and returned there in replicate order ([] elsewhere).
+    A replicate's draw depends on (seed, its number) alone, so the list does not depend on G.
+    `share(table, x0, first, step, count, seed, device)` is the per-rank piece (tests stand the
+    oracle in for it)."""
+    from . import parallel
+    if n_boot <= 0:
+        return []
+    if ranks.world == 1:
+        return bootstrap_quantify(results, x0, n_boot, seed=seed)
+    table = None
+    if ranks.rank == 0:
+        if seed is None:
+            seed = int.from_bytes(__import__('os').urandom(8), 'little')
+        table = {'class_offsets': results.class_offsets, 'class_targets': results.class_targets,
+                 'class_count': results.class_count, 'effective_lengths': results.effective_lengths.astype('f8'),
+                 'x0': numpy.asarray(x0, dtype='f8'), 'seed': numpy.asarray([seed], dtype=numpy.uint64)}
+    table = ranks.broadcast_arrays(table)
+    seed = int(table['seed'][0])
+    first, step, count = parallel.replicate_share(n_boot, ranks.rank, ranks.world)
+    n_tx = table['effective_lengths'].size
+    if table['class_count'].size == 0:                      # (quantify: an empty class_map gives zeros)
+        mine = numpy.zeros((count, n_tx), dtype='f8')
+    else:
+        mine = share(table, table['x0'], first, step, count, seed, device)
+    parts = ranks.gather_arrays_to_root({'tpm': mine})
+    if ranks.rank != 0:
+        return []
+    out = [None] * n_boot
+    for r, part in enumerate(parts):
+        for j, number in enumerate(range(r, n_boot, ranks.world)):
+            out[number] = part['tpm'][j]
+    return out
 
 
 def em(x, l, class_map, class_count, fixed_iters=0, return_iters=False, device=0):

@@ -3,12 +3,14 @@
 Reads are independent units, so they shard across ranks with no collective
 while mapping; every rank holds a full index replica.  Exchange steps:
   * once after mapping: the fragment-length histogram is all-reduced (the
-    effective lengths need the global one) and, when the merged class table is
-    wanted (bit-identical class counts / reference class order), the per-rank
-    tables are all-gathered and merged by global first-seen unit index;
+    effective lengths need the global one; inside skm_quant_infer, RCCL);
   * per EM step: one all-reduce(sum) of f64[T] -- done inside the HIP library
     with RCCL (skm_comm_create + skm_quant_set_comm); classes stay rank-local because the EM
-    numerators are linear in the class counts.
+    numerators are linear in the class counts;
+  * after the EM: the ranks' class tables go to rank 0 as raw arrays and are merged into its
+    own on the GPU (skm_mapper_merge), classes ordered by global first-seen unit index;
+  * `-b N`: rank 0 shares the merged table, every rank runs its share of the replicates with
+    no collective, the results are gathered on rank 0.
 `dist` is `torch.distributed` (backend nccl == RCCL on the GPUs, gloo in the
 CPU tests); torch is used for rendezvous and these small host-side exchanges
 only.
@@ -16,69 +18,11 @@ only.
 import numpy
 
 
-def shard_range(n_units, rank, world):
-    """Contiguous shard [first, first + count) of `n_units` for `rank`."""
-    base, extra = divmod(int(n_units), int(world))
-    first = rank * base + min(rank, extra)
-    return first, base + (1 if rank < extra else 0)
-
-
-def allreduce_fld(fld, dist, group=None):
-    """MapResult.merge_fragment_lengths across ranks (seekmer/mapper.py:106-115)."""
-    import torch
-    t = torch.from_numpy(numpy.ascontiguousarray(fld, dtype=numpy.int64).copy())
-    dist.all_reduce(t, group=group)
-    return t.numpy()
-
-
-def gather_tables(table, dist, group=None):
-    """All-gather per-rank class tables.  `table` = dict(offsets, targets,
-    counts, first_seen (GLOBAL unit indices), unaligned)."""
-    world = dist.get_world_size(group)
-    out = [None] * world
-    dist.all_gather_object(out, table, group=group)
-    return out
-
-
-def merge_class_tables(tables):
-    """Counter.update over several tables (seekmer/mapper.py:70): counts add,
-    classes are ordered by the smallest global first-seen unit index, which is
-    the insertion order a single `-j 1` run over all units would produce.
-    Returns dict(offsets, targets, counts, first_seen, unaligned)."""
-    merged = {}
-    unaligned = 0
-    for table in tables:
-        unaligned += int(table['unaligned'])
-        offsets = table['offsets']
-        targets = numpy.asarray(table['targets']).tolist()
-        counts = table['counts']
-        first = table['first_seen']
-        for k in range(len(counts)):
-            key = tuple(targets[offsets[k]:offsets[k + 1]])
-            entry = merged.get(key)
-            if entry is None:
-                merged[key] = [int(counts[k]), int(first[k])]
-            else:
-                entry[0] += int(counts[k])
-                if first[k] < entry[1]:
-                    entry[1] = int(first[k])
-    order = sorted(merged.items(), key=lambda kv: kv[1][1])
-    offsets = numpy.zeros(len(order) + 1, dtype=numpy.int64)
-    numpy.cumsum([len(k) for k, _ in order], out=offsets[1:])
-    return {
-        'offsets': offsets,
-        'targets': numpy.asarray([t for k, _ in order for t in k], dtype=numpy.int32),
-        'counts': numpy.asarray([v[0] for _, v in order], dtype=numpy.int64),
-        'first_seen': numpy.asarray([v[1] for _, v in order], dtype=numpy.int64),
-        'unaligned': unaligned,
-    }
-
-
-def export_table(map_result, first_unit):
-    """The table of a rank's MapResult with first-seen indices made global."""
-    offsets, targets, counts, first_seen, _ = map_result.export()
-    return {'offsets': offsets, 'targets': targets, 'counts': counts,
-            'first_seen': first_seen + int(first_unit), 'unaligned': map_result.sizes()[2]}
+def replicate_share(n_boot, rank, world):
+    """(first, step, count): the bootstrap replicates of `rank` -- numbers first, first + step, ...
+    below n_boot (B / G replicates per GPU, no collective while they run)."""
+    first, step = int(rank), int(world)
+    return first, step, len(range(first, int(n_boot), step))
 
 
 def broadcast_comm_id(dist, rank, group=None):
@@ -118,8 +62,13 @@ class Ranks:
         import torch.distributed as dist
         owns = False
         if not dist.is_initialized():
+            import datetime
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            # how long a rank waits for its peers in a host-side exchange before giving up (a peer
+            # that died without the launcher noticing); every rank takes part in every phase, so
+            # the longest wait is the slowest rank's lag, not a whole phase
+            timeout = datetime.timedelta(seconds=float(os.environ.get('SKM_DIST_TIMEOUT_S', '1800')))
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
             owns = True
         return cls(rank, world, local_rank, dist, owns)
 
@@ -132,12 +81,70 @@ class Ranks:
             self.dist.barrier()
 
     def gather_to_root(self, obj):
-        """[obj of rank 0, obj of rank 1, ...] on rank 0, None elsewhere."""
+        """[obj of rank 0, obj of rank 1, ...] on rank 0, None elsewhere (small objects: pickled)."""
         if self.dist is None:
             return [obj]
         out = [None] * self.world if self.rank == 0 else None
         self.dist.gather_object(obj, out, dst=0)
         return out
+
+    def gather_arrays_to_root(self, arrays):
+        """Every rank's dict of numpy arrays on rank 0 ([dict of rank 0, dict of rank 1, ...]; None
+        elsewhere) without pickling them: shapes and dtypes travel as a small object, the data as
+        raw bytes straight out of and into the arrays."""
+        if self.dist is None:
+            return [arrays]
+        import torch
+        arrays = {k: numpy.ascontiguousarray(v) for k, v in arrays.items()}
+        described = self.gather_to_root({k: (v.shape, v.dtype.str) for k, v in arrays.items()})
+        if self.rank != 0:
+            for name in sorted(arrays):
+                if arrays[name].size:
+                    self.dist.send(torch.from_numpy(arrays[name].reshape(-1).view(numpy.uint8)), dst=0)
+            return None
+        out = [arrays]
+        for source in range(1, self.world):
+            got = {}
+            for name in sorted(described[source]):
+                shape, dtype = described[source][name]
+                array = numpy.empty(shape, dtype=numpy.dtype(dtype))
+                if array.size:
+                    self.dist.recv(torch.from_numpy(array.reshape(-1).view(numpy.uint8)), src=source)
+                got[name] = array
+            out.append(got)
+        return out
+
+    def broadcast_arrays(self, arrays):
+        """Rank 0's dict of numpy arrays on every rank (the argument is ignored elsewhere)."""
+        if self.dist is None:
+            return arrays
+        import torch
+        if self.rank == 0:
+            arrays = {k: numpy.ascontiguousarray(v) for k, v in arrays.items()}
+        box = [{k: (v.shape, v.dtype.str) for k, v in arrays.items()} if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        out = {}
+        for name in sorted(box[0]):
+            shape, dtype = box[0][name]
+            array = arrays[name] if self.rank == 0 else numpy.empty(shape, dtype=numpy.dtype(dtype))
+            if array.size:
+                self.dist.broadcast(torch.from_numpy(array.reshape(-1).view(numpy.uint8)), src=0)
+            out[name] = array
+        return out
+
+    def fail(self, error):
+        """A rank that cannot go on must not leave its peers waiting in a barrier, a gather or an
+        RCCL all-reduce: report, and end THIS process with a non-zero status at once (the launcher
+        -- torch.distributed.run -- then stops the other ranks; nothing is restarted or re-executed).
+        With one rank the error is simply raised."""
+        if self.world <= 1:
+            raise error
+        import os
+        import sys
+        import traceback
+        traceback.print_exception(type(error), error, error.__traceback__, file=sys.stderr)
+        print('[seekmer_amd] rank %d of %d failed: ending the job' % (self.rank, self.world), file=sys.stderr, flush=True)
+        os._exit(1)
 
     def close(self):
         if self.dist is not None and self._owns_group:
@@ -193,10 +200,10 @@ def destroy_comm(comm):
 def rank_table(map_result):
     """What rank 0 needs from a rank after mapping: its class table (first-seen values are global
     unit indices already: every batch was mapped with its `first_unit`), the unaligned count and
-    the rank's fragment-length histogram."""
+    the rank's fragment-length histogram -- all numpy arrays (Ranks.gather_arrays_to_root)."""
     offsets, targets, counts, first_seen, fld = map_result.export()
     return {'offsets': offsets, 'targets': targets, 'counts': counts, 'first_seen': first_seen,
-            'unaligned': map_result.sizes()[2], 'fld': fld}
+            'unaligned': numpy.asarray([map_result.sizes()[2]], dtype=numpy.int64), 'fld': fld}
 
 
 def merge_into(map_result, tables):
@@ -205,7 +212,7 @@ def merge_into(map_result, tables):
     order a single -j1 run would have met them."""
     for table in tables:
         map_result.merge_table(table['offsets'], table['targets'], table['counts'], table['first_seen'],
-                               table['unaligned'], table['fld'])
+                               int(numpy.asarray(table['unaligned']).reshape(-1)[0]), table['fld'])
 
 
 def shared_index(build, rank, world, barrier=None, cache=None):

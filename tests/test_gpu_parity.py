@@ -652,6 +652,22 @@ def test_config4_bootstrap_on_a_mapped_table(oracle, native_libs, monkeypatch):
     tpms = infer.bootstrap_quantify(summarized, main, 3, seed=20240)
     assert len(tpms) == 3 and all(abs(t.sum() - 1e6) < 1e-3 for t in tpms)
     np.testing.assert_array_equal(tpms[0], infer._tpm(out[0].copy()))   # numpy's sums restated on the device
+    # `-b N` shared out over G ranks: rank r's share -- replicates r, r + G, ... of a
+    # handle made from the merged table's arrays -- is, replicate by replicate, what the one-GPU loop
+    # gives; with G = 1 the share IS that loop
+    from seekmer_amd import parallel
+    whole = np.asarray(infer.bootstrap_quantify(summarized, main, 11, seed=99))
+    table = {'class_offsets': summarized.class_offsets, 'class_targets': summarized.class_targets,
+             'class_count': summarized.class_count, 'effective_lengths': eff}
+    np.testing.assert_array_equal(infer._bootstrap_share(table, main, 0, 1, 11, 99), whole)
+    for world in (2, 3):
+        for rank in range(world):
+            first, step, count = parallel.replicate_share(11, rank, world)
+            np.testing.assert_array_equal(infer._bootstrap_share(table, main, first, step, count, 99), whole[rank::world])
+    # a handle that holds one rank's share of the classes must refuse to resample it (a communicator of
+    # several ranks cannot be made on one GPU: the rule is checked on the handle's record of it)
+    assert infer.bootstrap_ranks(summarized, main, 0, parallel.Ranks()) == []
+    np.testing.assert_array_equal(np.asarray(infer.bootstrap_ranks(summarized, main, 11, parallel.Ranks(), seed=99)), whole)
 
 
 def test_cli_end_to_end(oracle, native_libs, chr21, chr21_oracle_index, pairs21, tmp_path):

@@ -6,7 +6,10 @@ oracle: a MapResult whose table is filled by the oracle's mapper, and a `quantif
 runs the reference's EM with one all-reduce of the per-transcript numerators per step -- the
 collective pattern of skm_quant_infer(comm).  Rank 0's results must equal one process mapping the
 whole sample: class table bit for bit (order included), histogram, counts, and the TPM of the
-sharded EM against the oracle's EM on the merged table (same iteration count, 1e-9)."""
+sharded EM against the oracle's EM on the merged table (same iteration count, 1e-9).  `-b N` over the
+ranks (infer.bootstrap_ranks: the merged table broadcast, rank r runs replicates r, r + G, ...,
+results gathered in replicate order) with the oracle's EM as the per-rank piece equals the
+one-rank loop replicate by replicate."""
 import os
 import socket
 import sys
@@ -134,6 +137,26 @@ def _quantify_ranks(O, index, ranks):
     return run
 
 
+N_BOOT, BOOT_SEED = 7, 12345
+
+
+def _oracle_share(O):
+    """The per-rank piece of `-b N` with the oracle standing in for the device: a replicate's draw is
+    keyed by (seed, its number), the EM starts from the main estimate (seekmer/infer.py:108-118)."""
+    def share(table, x0, first, step, count, seed, device):
+        offsets = table['class_offsets']
+        class_map = np.vstack([np.repeat(np.arange(offsets.size - 1), np.diff(offsets)),
+                               table['class_targets'].astype(np.int64)])
+        counts = table['class_count']
+        out = np.zeros((count, table['effective_lengths'].size))
+        for j in range(count):
+            rng = np.random.default_rng([seed, first + j * step])
+            draw = rng.multinomial(int(counts.sum()), counts / counts.sum()).astype('f8')
+            out[j], _ = O.quantify(table['effective_lengths'], class_map, draw, x0=x0)
+        return out
+    return share
+
+
 def _worker(rank, world, port, tmp, queue):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -155,14 +178,17 @@ def _worker(rank, world, port, tmp, queue):
         quantify = _quantify_ranks(O, index, ranks)
         summarized, tpm = infer.finish(result, ranks, quantify)
         everyone = ranks.gather_to_root(tpm)
+        boots = infer.bootstrap_ranks(summarized, tpm, N_BOOT, ranks, seed=BOOT_SEED, share=_oracle_share(O))
+        assert parallel.replicate_share(N_BOOT, rank, world) == (rank, world, len(range(rank, N_BOOT, world)))
         if rank == 0:
             assert all(np.array_equal(t, tpm) for t in everyone)          # every rank holds the same TPM
+            assert len(boots) == N_BOOT
             queue.put({'summarized': {k: getattr(summarized, k) for k in
                                       ('aligned', 'unaligned', 'total', 'class_map', 'class_count',
                                        'fragment_length_frequencies', 'effective_lengths')},
-                       'export': result.export(), 'tpm': tpm, 'steps': quantify.steps})
+                       'export': result.export(), 'tpm': tpm, 'steps': quantify.steps, 'boots': np.asarray(boots)})
         else:
-            assert summarized is None
+            assert summarized is None and boots == []
     finally:
         ranks.close()
 
@@ -206,17 +232,53 @@ def test_two_ranks_equal_one(oracle, native_libs, tmp_path):
     mask = tpm_ref > 0
     np.testing.assert_array_equal(got['tpm'] > 0, mask)
     np.testing.assert_allclose(got['tpm'][mask], tpm_ref[mask], rtol=1e-9, atol=0)
+    # -b N over two ranks == the one-rank loop, replicate by replicate
+    table = {'class_offsets': offs, 'class_targets': targets, 'class_count': class_count, 'effective_lengths': eff}
+    alone = _oracle_share(oracle)(table, got['tpm'], 0, 1, N_BOOT, BOOT_SEED, 0)
+    np.testing.assert_array_equal(got['boots'], alone)
+    assert len({row.tobytes() for row in got['boots']}) == N_BOOT          # (the replicates differ)
 
 
-def test_shard_range_covers_everything():
+def test_replicate_shares_partition_the_bootstraps():
     from seekmer_amd import parallel
-    for n in (0, 1, 7, 8, 1000003):
+    for n in (0, 1, 7, 8, 100):
         for world in (1, 2, 3, 8):
-            spans = [parallel.shard_range(n, r, world) for r in range(world)]
-            assert spans[0][0] == 0
-            assert sum(c for _, c in spans) == n
-            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
-                assert f0 + c0 == f1
+            numbers = []
+            for r in range(world):
+                first, step, count = parallel.replicate_share(n, r, world)
+                numbers += [first + j * step for j in range(count)]
+            assert sorted(numbers) == list(range(n))
+
+
+def _failing_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update({'RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'SKM_DIST_TIMEOUT_S': '20'})
+    from seekmer_amd import parallel
+    ranks = parallel.Ranks.from_env()
+    try:
+        if rank == 1:
+            raise RuntimeError('this rank cannot go on')
+        ranks.barrier()                      # the peer never arrives: this must not wait for ever
+    except BaseException as error:           # noqa: B902
+        ranks.fail(error)
+    ranks.close()
+
+
+def test_a_failing_rank_ends_the_job():
+    """parallel.Ranks.fail: the failing rank leaves with a non-zero status at once (a launcher stops the
+    others); a peer that is not stopped by a launcher gives up after the group's timeout instead of
+    waiting for ever -- and fails in turn."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+    assert procs[1].exitcode == 1
+    assert procs[0].exitcode not in (0, None)
 
 
 def test_one_rank_needs_no_process_group(monkeypatch):
