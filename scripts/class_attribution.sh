@@ -1,0 +1,30 @@
+#!/bin/bash
+# Where class_insert_kernel's time goes: the product build against timing-only builds without its
+# atomics, without its probe, and without both (scripts/build_variant.sh cxN "-DSKM_CLASS_EXPERIMENT=N"
+# skm_classes.hip), each under rocprofv3 --kernel-trace --stats over scripts/profile_map.py (one
+# 10 M-pair batch mapped on a fresh table, then once more on the table that holds every class).
+#   bash scripts/class_attribution.sh OUTDIR
+OUT=$1
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $ROOT/scripts/profile_map.py --reps 1 --cache /tmp/skm_idx.npz > $OUT/warm.log 2>&1
+for name in base cx1 cx2 cx3; do
+  lib=$ROOT/seekmer_amd/libseekmer_hip_$name.so
+  [ "$name" = base ] && lib=$ROOT/seekmer_amd/libseekmer_hip.so
+  export SKM_HIP_LIB=$lib
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/$name --output-format csv -- \
+      python3 $ROOT/scripts/profile_map.py --reps 3 --again --cache /tmp/skm_idx.npz > $OUT/$name.log 2>&1 || { echo "$name failed"; tail -3 $OUT/$name.log; }
+  python3 - $OUT/$name $name <<'P'
+import csv, glob, sys
+rows = {}
+for path in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
+    for r in csv.DictReader(open(path)):
+        n = r['Kernel_Name']
+        for key in ('class_insert', 'class_verify', 'class_commit', 'map_units'):
+            if key in n:
+                rows.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
+print(sys.argv[2], ' '.join('%s: fresh %.3f ms, every class known %.3f ms' % (k, min(v[:-1]), v[-1]) for k, v in sorted(rows.items()) if len(v) > 1), flush=True)
+P
+  find $OUT/$name -name "*.csv" -size +1M -delete
+done

@@ -365,7 +365,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     if (n_slots <= 0 || (n_slots & (n_slots - 1)) || n_slots > (1LL << 31))
         return fail(SKM_ERR_ARG, "k-mer table size %lld is not a power of two <= 2^31", (long long)n_slots);
     if (n_contigs <= 0 || n_bases < ALIGN_LENGTH || n_targets < 0 || n_bases >= (1LL << 31)
-            || n_targets >= (1LL << 30) || n_contigs >= (1LL << 27))
+            || n_targets + 16 * n_contigs >= (1LL << 30) || n_contigs >= (1LL << 26))
         return fail(SKM_ERR_ARG, "bad index sizes");
     int n_dev = 0;
     SKM_TRY(skm_device_count(&n_dev));
@@ -440,9 +440,8 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     skm_index *ix = new skm_index();
     ix->device = device;
     char *d_ascii = nullptr;
-    void *d_contigs48 = nullptr;
     auto undo = on_exit([&]() {                 // any early return below: nothing is left behind
-        (void)hipFree(d_ascii); (void)hipFree(d_contigs48);
+        (void)hipFree(d_ascii);
         skm_index_destroy(ix);
     });
     hipDeviceProp_t prop;
@@ -450,19 +449,42 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     ix->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int64_t n_words = (n_bases + 31) / 32 + 1;
     HIP_TRY(hipMalloc(&ix->kmers, (size_t)n_slots * sizeof(IndexEntry)));
-    HIP_TRY(hipMalloc(&ix->contigs, (size_t)n_contigs * sizeof(DevContig)));
-    HIP_TRY(hipMalloc(&ix->targets, (size_t)std::max<int64_t>(n_targets, 1) * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&ix->seq2, (size_t)n_words * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&d_ascii, (size_t)n_bases));
     HIP_TRY(hipMemcpy(ix->kmers, kmers, (size_t)n_slots * sizeof(IndexEntry), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&d_contigs48, (size_t)n_contigs * sizeof(ContigEntry)));
-    HIP_TRY(hipMemcpy(d_contigs48, contigs, (size_t)n_contigs * sizeof(ContigEntry), hipMemcpyHostToDevice));
-    launch_pack_contigs(d_contigs48, n_contigs, ix->contigs, nullptr);
-    if (n_targets) {                // keep the signed entries only (half the sectors per slice)
-        std::vector<int32_t> entries((size_t)n_targets);
+    int64_t n_overflow = 0;
+    {   // contig rows (skm_device.h: DevContig) and, behind them in the same allocation, the target
+        // slices that do not fit their row; of every target only the signed entry is kept
+        std::vector<DevContig> rows((size_t)n_contigs);
+        std::vector<int32_t> overflow;
         const Coord *ht = (const Coord *)targets;
-        for (int64_t i = 0; i < n_targets; ++i) entries[(size_t)i] = ht[i].entry;
-        HIP_TRY(hipMemcpy(ix->targets, entries.data(), (size_t)n_targets * sizeof(int32_t), hipMemcpyHostToDevice));
+        const int64_t row_words = (int64_t)sizeof(DevContig) / 4;
+        for (int64_t c = 0; c < n_contigs; ++c) {
+            DevContig &d = rows[(size_t)c];
+            memset(&d, 0, sizeof(d));
+            d.offset = (int32_t)hc[c].offset;
+            d.length = (int32_t)hc[c].length;
+            d.target_length = (int32_t)hc[c].target_length;
+            d.first_kmer = hc[c].first_kmer;
+            d.last_kmer = hc[c].last_kmer;
+            const int64_t first = hc[c].target_offset, count = hc[c].target_length;
+#if SKM_CONTIG_INLINE
+            if (count <= CONTIG_INLINE_TARGETS) {
+                d.target_offset = (int32_t)(c * row_words + (row_words - CONTIG_INLINE_TARGETS));
+                for (int64_t i = 0; i < count; ++i) d.targets[i] = ht[first + i].entry;
+                continue;
+            }
+#endif
+            d.target_offset = (int32_t)(n_contigs * row_words + (int64_t)overflow.size());
+            for (int64_t i = 0; i < count; ++i) overflow.push_back(ht[first + i].entry);
+        }
+        n_overflow = (int64_t)overflow.size();
+        const size_t row_bytes = (size_t)n_contigs * sizeof(DevContig);
+        HIP_TRY(hipMalloc(&ix->contigs, row_bytes + (size_t)(n_overflow + 16) * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(ix->contigs, rows.data(), row_bytes, hipMemcpyHostToDevice));
+        if (n_overflow)
+            HIP_TRY(hipMemcpy((char *)ix->contigs + row_bytes, overflow.data(), (size_t)n_overflow * sizeof(int32_t),
+                              hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(d_ascii, sequences, (size_t)n_bases, hipMemcpyHostToDevice));
     launch_pack_sequences(d_ascii, n_bases, (uint64_t *)ix->seq2, n_words, nullptr);
@@ -470,8 +492,6 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(d_ascii));
     d_ascii = nullptr;
-    HIP_TRY(hipFree(d_contigs48));
-    d_contigs48 = nullptr;
     ix->n_slots = n_slots;
     ix->d.kmers = (const IndexEntry *)ix->kmers;
     ix->d.slot_mask = (uint32_t)(n_slots - 1);
@@ -479,13 +499,13 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     ix->d.n_contigs = n_contigs;
     ix->d.seq2 = (const uint64_t *)ix->seq2;
     ix->d.n_bases = n_bases;
-    ix->d.targets = (const int32_t *)ix->targets;
+    ix->d.targets = (const int32_t *)ix->contigs;       // (rows and overflow slices as one int32 array)
     ix->d.n_targets = n_targets;
     ix->d.max_target_count = (int32_t)std::max<int64_t>(max_tc, 1);
     ix->d.edge_windows = edge_windows ? 1 : 0;
     ix->d.sorted_targets = sorted_targets ? 1 : 0;
     ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(DevContig)
-                + n_targets * (int64_t)sizeof(int32_t) + n_words * 8;
+                + n_overflow * (int64_t)sizeof(int32_t) + n_words * 8;
     {   // the same set of k-mers by bucket (skm_device.h: DevBucket): about one k-mer per bucket
         const int64_t occupied = n_slots - empty;
         uint64_t n_buckets = 16;

@@ -66,20 +66,27 @@ __device__ __forceinline__ uint64_t probe_claim(const ClassTable &t, unsigned lo
     return ~0ULL;
 }
 
-// probe_claim continued from a slot whose (key, first_seen) pair has been read already
+// probe_claim continued from a slot that has been read already (all 32 bytes: key, first_seen,
+// count, tuple); `stored` returns the tuple word of the slot the key was found in -- >= 0 once the
+// class's tuple is in the arena, which it is for every class of an earlier batch
 __device__ __forceinline__ uint64_t probe_claim_from(const ClassTable &t, unsigned long long key,
-                                                     ulonglong2 head, bool &claimed, uint64_t limit,
-                                                     unsigned long long &seen)
+                                                     ulonglong2 head, long long tuple_word, bool &claimed,
+                                                     uint64_t limit, unsigned long long &seen, long long &stored)
 {
     uint64_t slot = key & t.slot_mask;
     claimed = false;
     if (limit > t.slot_mask + 1) limit = t.slot_mask + 1;
     for (uint64_t n = 0; n < limit; ++n) {
-        if (n) head = *reinterpret_cast<const ulonglong2 *>(&t.slots[slot]);
+        if (n) {
+            head = *reinterpret_cast<const ulonglong2 *>(&t.slots[slot]);
+            tuple_word = t.slots[slot].tuple;
+        }
         unsigned long long cur = head.x;
         seen = head.y;
+        stored = tuple_word;
         if (cur == 0) {
             cur = atomicCAS(&t.slots[slot].key, 0ULL, key);
+            stored = -1;
             if (cur == 0) { claimed = true; return slot; }
         }
         if (cur == key) return slot;
@@ -88,12 +95,20 @@ __device__ __forceinline__ uint64_t probe_claim_from(const ClassTable &t, unsign
     return ~0ULL;
 }
 
-// Records are taken INSERT_WIDTH at a time per lane: their keys, then the home slots of all of
-// them, are fetched before any is looked at -- the chain key -> slot -> atomic of one record
-// runs under the chains of the others (one record per iteration left the kernel waiting on a
-// single dependent miss per lane; the atomics themselves run at the fabric's ~20 G/s for
-// scattered addresses).
+// Records are taken INSERT_WIDTH at a time per lane: everything a record's chain needs from the
+// batch (key, unit, tuple word), then the home slots of all of them, are fetched before any is
+// looked at -- the chain key -> slot -> atomic of one record runs under the chains of the others.
+// A record that lands on a class whose tuple is already in the arena (every class of an earlier
+// batch) is verified on the spot: the slot's tuple word came with the probe (same 32-byte
+// sector), so class_verify's second random pass over the table is only left with the records that
+// met a class created in this very launch (unit_slot >= 0; the others leave -1).
 constexpr int INSERT_WIDTH = 4;
+// Timing experiments only (scripts/build_variant.sh; the results of these builds are wrong):
+// 1 = no count / first-seen atomics, 2 = no probe (every record "found" in its home slot, no CAS),
+// 3 = neither: what is left is the streaming part of the kernel.
+#ifndef SKM_CLASS_EXPERIMENT
+#define SKM_CLASS_EXPERIMENT 0
+#endif
 
 __global__ void __launch_bounds__(256)
 class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot,
@@ -105,21 +120,30 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     if (threadIdx.x == 0) s_unaligned = 0;
     __syncthreads();
     unsigned int unaligned = 0;
+    bool all_same = true;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // (u walks the batch's RECORDS, skm_kernels.h: MapBatch; unit_slot / unit_claim are by record)
     for (int64_t u0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u0 < b.n_units; u0 += INSERT_WIDTH * stride) {
-        unsigned long long key[INSERT_WIDTH];
+        unsigned long long key[INSERT_WIDTH], mine_at[INSERT_WIDTH];
         ulonglong2 head[INSERT_WIDTH];
+        long long tuple_word[INSERT_WIDTH];
+        int32_t unit_of[INSERT_WIDTH];
         bool live[INSERT_WIDTH];
 #pragma unroll
         for (int k = 0; k < INSERT_WIDTH; ++k) {
             const int64_t u = u0 + k * stride;
             live[k] = u < b.n_units && !(retry_deferred && unit_slot[u] != -2);
             key[k] = live[k] ? b.rec_key[u] : 0;
+            unit_of[k] = live[k] ? b.rec_unit[u] : 0;
+            mine_at[k] = live[k] ? b.rec_tuple[u] : 0;
         }
 #pragma unroll
-        for (int k = 0; k < INSERT_WIDTH; ++k)
-            head[k] = *reinterpret_cast<const ulonglong2 *>(&t.slots[key[k] & t.slot_mask]);   // (key 0: slot 0, unused)
+        for (int k = 0; k < INSERT_WIDTH; ++k) {
+            const ClassSlot *home = &t.slots[key[k] & t.slot_mask];          // (key 0: slot 0, unused)
+            if (SKM_CLASS_EXPERIMENT & 2) { head[k] = ulonglong2{key[k], 0ULL}; tuple_word[k] = -1; continue; }
+            head[k] = *reinterpret_cast<const ulonglong2 *>(home);
+            tuple_word[k] = home->tuple;
+        }
 #pragma unroll
         for (int k = 0; k < INSERT_WIDTH; ++k) {
             const int64_t u = u0 + k * stride;
@@ -134,18 +158,33 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
                 } else {
                     bool claimed;
                     unsigned long long seen = ~0ULL;
-                    const uint64_t slot = probe_claim_from(t, key[k], head[k], claimed, CLASS_PROBE_LIMIT, seen);
+                    long long stored = -1;
+                    const uint64_t slot = probe_claim_from(t, key[k], head[k], tuple_word[k], claimed, CLASS_PROBE_LIMIT,
+                                                           seen, stored);
                     if (slot == ~0ULL) {          // deferred: counted after the table has grown
                         atomicAdd(t.n_deferred, 1ULL);
                         where = -2;
                     } else {
                         // the creator of a class stores its tuple later (class_commit_kernel): one
                         // class (bits 40+) and n arena ids (bits 0-39), placed by a device-wide scan
-                        if (claimed) claim = (1ULL << 40) | (b.rec_tuple[u] >> 40);
-                        atomicAdd(&t.slots[slot].count, 1ULL);
-                        const unsigned long long unit = (unsigned long long)(unit_base + b.rec_unit[u]);
-                        if (claimed || seen > unit) atomicMin(&t.slots[slot].first_seen, unit);
+                        if (claimed) claim = (1ULL << 40) | (mine_at[k] >> 40);
+                        const unsigned long long unit = (unsigned long long)(unit_base + unit_of[k]);
+                        if (!(SKM_CLASS_EXPERIMENT & 1)) {
+                            atomicAdd(&t.slots[slot].count, 1ULL);
+                            if (claimed || seen > unit) atomicMin(&t.slots[slot].first_seen, unit);
+                        }
                         where = (int64_t)slot;
+                        if (stored >= 0) {        // the class's tuple is in the arena: compare now
+                            const int n = (int)(mine_at[k] >> 40);
+                            bool same = tuple_len(stored) == n;
+                            if (same) {
+                                const int32_t *mine = b.unit_entries + (mine_at[k] & ((1ULL << 40) - 1));
+                                const int32_t *ref = t.arena + tuple_offset(stored);
+                                for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
+                            }
+                            all_same &= same;
+                            where = -1;           // (nothing left for class_verify)
+                        }
                     }
                 }
                 unit_slot[u] = where;
@@ -153,6 +192,7 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
             unit_claim[u] = claim;                // (a record counted in an earlier pass: only its claim is cleared)
         }
     }
+    if (!all_same) atomicExch(t.error, SKM_ERR_COLLISION);
     if (unaligned) atomicAdd(&s_unaligned, unaligned);
     __syncthreads();
     if (threadIdx.x == 0 && s_unaligned) atomicAdd(t.n_unaligned, (unsigned long long)s_unaligned);

@@ -26,15 +26,39 @@ struct ContigEntry {                                             // _common.pxd:
     int64_t target_offset, target_length;
 };
 
-// Contig record as the kernels read it: the 48-byte reference row re-packed
-// at upload to 32 bytes (two per 64-byte sector, never straddling one).  The
-// mapper runs at the chip's random sector-request ceiling, so what counts is
-// how many sectors a contig visit touches.
+// Contig record as the kernels read it.  The mapper runs at the chip's random sector-request
+// ceiling, so what counts is how many 64-byte sectors a contig visit touches -- and a visit that
+// merges or copies the contig's target list (KMerIndex.map_contig / _filter_on_contig,
+// _common.pyx:143-235) used to touch two, one after the other: the row, then the slice of
+// `targets` it points to.  The 48-byte reference row is therefore re-packed at upload to ONE
+// sector that carries the contig's first CONTIG_INLINE_TARGETS signed target entries behind the
+// row's fields (nine slices in ten have no more than eight): the row's target_offset points into
+// its own sector, the list arrives with the row, and a merge is one round trip instead of two.
+// Longer slices live behind the rows in the same allocation; `DevIndex::targets` addresses rows
+// and overflow alike as one int32 array (row c's inline entries are elements 16 c + 8 .. 16 c + 15).
+// SKM_CONTIG_INLINE=0 builds the former layout (32-byte rows, all slices in a separate array).
+#ifndef SKM_CONTIG_INLINE
+#define SKM_CONTIG_INLINE 1
+#endif
+#if SKM_CONTIG_INLINE
+constexpr int CONTIG_INLINE_TARGETS = 8;
+constexpr int CONTIG_SHIFT = 6;
+struct alignas(64) DevContig {
+    int32_t offset, length;            // into the pooled bases
+    int32_t target_offset, target_length;
+    uint64_t first_kmer, last_kmer;
+    int32_t targets[CONTIG_INLINE_TARGETS];
+};
+#else
+constexpr int CONTIG_INLINE_TARGETS = 0;
+constexpr int CONTIG_SHIFT = 5;
 struct alignas(32) DevContig {
     int32_t offset, length;            // into the pooled bases
     int32_t target_offset, target_length;
     uint64_t first_kmer, last_kmer;
 };
+#endif
+static_assert(sizeof(DevContig) == (1u << CONTIG_SHIFT), "contig_at shifts by CONTIG_SHIFT");
 
 // The k-mer table as the mapper probes it.  The reference's table (linear
 // probing from a SipHash home slot, _common.pyx:54-97) is a set: a built index
@@ -71,7 +95,7 @@ struct DevIndex {
     int64_t n_contigs;
     const uint64_t *seq2;      // 2-bit packed pooled bases, one zero pad word
     int64_t n_bases;
-    const int32_t *targets;    // signed transcript entries (Coord.entry of the reference rows)
+    const int32_t *targets;    // signed transcript entries (Coord.entry of the reference rows); see DevContig
     int64_t n_targets;
     int32_t max_target_count;
     int32_t edge_windows;      // first_kmer/last_kmer agree with the pooled bases on every contig
@@ -86,11 +110,11 @@ __device__ __forceinline__ Coord invalid_coord() { return Coord{0, -1}; }  // _c
 // Row `index` of the contig table through a 32-bit byte offset from the
 // (wave-uniform) base pointer: scalar base + vector offset addressing instead
 // of a 64-bit address computation per access (skm_index_create bounds
-// n_contigs by 2^27).
+// n_contigs by 2^26).
 __device__ __forceinline__ const DevContig &contig_at(const DevIndex &ix, int32_t index)
 {
     return *reinterpret_cast<const DevContig *>(reinterpret_cast<const char *>(ix.contigs)
-                                                + ((uint32_t)index << 5));
+                                                + ((uint32_t)index << CONTIG_SHIFT));
 }
 
 // _kmer.pxd:146-171: reverse the 2-bit groups of the 64-bit word, shift the

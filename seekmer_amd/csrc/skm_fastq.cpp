@@ -33,6 +33,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -442,10 +443,25 @@ struct skm_fastq {
             }
             const bool trace = getenv("SKM_FASTQ_TRACE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
-            skm_fastq_slab *slab = take_slab();
-            const size_t cap_before = slab->bases.cap;
-            const auto t1 = std::chrono::steady_clock::now();
-            build_batch(shard_rank + k * shard_world, slab);
+            skm_fastq_slab *slab = nullptr;
+            size_t cap_before = 0;
+            auto t1 = t0;
+            try {                              // (an allocation failure fails the reader, not the process)
+                slab = take_slab();
+                cap_before = slab->bases.cap;
+                t1 = std::chrono::steady_clock::now();
+                build_batch(shard_rank + k * shard_world, slab);
+            } catch (const std::bad_alloc &) {
+                if (!slab) slab = new (std::nothrow) skm_fastq_slab();
+                if (slab) slab->bases.failed = true;
+            }
+            if (!slab) {
+                std::lock_guard<std::mutex> hold(pm);
+                failed = true;
+                ready[k] = nullptr;
+                pcv.notify_all();
+                continue;
+            }
             if (trace)
                 fprintf(stderr, "[skm_fastq] batch %lld: slab %.1f ms (capacity %zu -> %zu), parse %.1f ms, %lld units\n", (long long)k,
                         std::chrono::duration<double, std::milli>(t1 - t0).count(), cap_before, slab->bases.cap,
@@ -574,6 +590,7 @@ static int next_parallel(skm_fastq *q, int64_t *n_units)
                 (long long)q->next_deliver);
     q->cur = q->ready[q->next_deliver];
     q->ready.erase(q->next_deliver);
+    if (!q->cur) { q->failed = true; return SKM_ERR_IO; }
     q->last_index = q->shard_rank + q->next_deliver * q->shard_world;
     q->last_read_len = q->cur->read_len;
     q->next_deliver++;

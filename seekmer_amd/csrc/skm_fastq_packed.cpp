@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -147,7 +148,7 @@ struct skm_fastq_packed {
     std::vector<Mapped> files;
     struct Item { int file, stream; size_t a, b; };          // file < 0: the end of a pair of files
     std::vector<Item> items;
-    struct Result { PackedOut *out = nullptr; size_t start = 0, end = 0; bool has_start = false; };
+    struct Result { PackedOut *out = nullptr; size_t start = 0, end = 0; bool has_start = false, broken = false; };
     std::mutex pm;
     std::condition_variable pcv;
     size_t next_claim = 0, next_deliver = 0;
@@ -197,7 +198,13 @@ struct skm_fastq_packed {
                 k = next_claim++;
             }
             Result r;
-            if (items[k].file >= 0) r = parse(items[k]);
+            try {                              // (an allocation failure fails the reader, not the process)
+                if (items[k].file >= 0) r = parse(items[k]);
+            } catch (const std::bad_alloc &) {
+                give_piece(r.out);
+                r = Result();
+                r.broken = true;
+            }
             {
                 std::lock_guard<std::mutex> hold(pm);
                 ready[k] = r;
@@ -328,7 +335,7 @@ extern "C" int skm_fastq_packed_next(void *reader, skm_packed_reads *piece)
             r = q->parse(it);
             q->next_deliver++;
         }
-        if (!r.out) { q->failed = true; return SKM_ERR_STATE; }
+        if (!r.out || r.broken) { q->failed = true; return SKM_ERR_STATE; }
         const Mapped &f = q->files[(size_t)it.file];
         size_t &pos = q->file_pos[(size_t)it.file];
         if (pos >= it.b) {                       // the walk before this range ran past it: nothing starts here

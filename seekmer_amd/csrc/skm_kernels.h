@@ -62,7 +62,6 @@ void launch_unpack_exceptions(const uint32_t *exc_reads, const uint32_t *exc_mas
 void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,
                          hipStream_t stream);
 void launch_offsets_uniform(int64_t *offsets, int64_t n_reads, int64_t read_len, hipStream_t stream);
-void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream);
 // build the bucket table from the reference table and check the reference probe (see DevBucket);
 // report: [0] placed [1] placed outside the home bucket [2] k-mers met twice [3] slots the
 // reference probe does not reach

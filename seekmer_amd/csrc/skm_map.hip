@@ -204,24 +204,6 @@ offsets_rebase_kernel(int64_t *offsets, int64_t n, int64_t base)
          r += (int64_t)gridDim.x * blockDim.x) offsets[r] -= base;
 }
 
-// reference contig rows (48 B) -> DevContig (32 B)
-__global__ void __launch_bounds__(256)
-pack_contigs_kernel(const ContigEntry *__restrict__ in, int64_t n, DevContig *__restrict__ out)
-{
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const ContigEntry c = in[i];
-        DevContig d;
-        d.offset = (int32_t)c.offset;
-        d.length = (int32_t)c.length;
-        d.target_offset = (int32_t)c.target_offset;
-        d.target_length = (int32_t)c.target_length;
-        d.first_kmer = c.first_kmer;
-        d.last_kmer = c.last_kmer;
-        out[i] = d;
-    }
-}
-
 // ------------------------------------------------- bucket table construction
 __global__ void __launch_bounds__(256)
 bucket_init_kernel(DevBucket *buckets, uint64_t n_buckets)
@@ -1380,14 +1362,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
             for (int i = 0; i < 2 + N_ACTIONS + 6; ++i) atomicAdd(&o[32 + i], cyc[i]);
         }
     }
-}
-
-void launch_pack_contigs(const void *contigs48, int64_t n_contigs, void *contigs32, hipStream_t stream)
-{
-    int64_t blocks = (n_contigs + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_contigs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
-                       (const ContigEntry *)contigs48, n_contigs, (DevContig *)contigs32);
 }
 
 void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *buckets, uint32_t bucket_mask,
