@@ -4,12 +4,12 @@
 # skm_classes.hip), each under rocprofv3 --kernel-trace --stats over scripts/profile_map.py (one
 # 10 M-pair batch mapped on a fresh table, then once more on the table that holds every class).
 #   bash scripts/class_attribution.sh OUTDIR
-OUT=$1
+OUT=$(realpath -m $1)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/scripts/profile_map.py --reps 1 --cache /tmp/skm_idx.npz > $OUT/warm.log 2>&1
-for name in base cx1 cx2 cx3; do
+for name in ${VARIANTS:-base cx1}; do
   lib=$ROOT/seekmer_amd/libseekmer_hip_$name.so
   [ "$name" = base ] && lib=$ROOT/seekmer_amd/libseekmer_hip.so
   export SKM_HIP_LIB=$lib

@@ -789,17 +789,30 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     bind_table(m, m->t.slot_mask + 1);
     const size_t scan_bytes = device_scan_u64_temp_bytes(n_units);
     SKM_TRY(m->scan_temp.ensure(scan_bytes + 16));
+    // A large batch on an empty table goes in two waves of records: once the classes of the first
+    // quarter are committed, most records of the rest land on a committed class and are verified
+    // inside class_insert (the slot's tuple word came with the probe); class_verify's second random
+    // pass over the table is left with the first wave and the records of classes new in the second.
+    const bool two_waves = m->host_classes == 0 && n_units >= (1 << 21);
     for (int pass = 0;; ++pass) {
         // insert -> prefix sum over the creators -> commit -> totals -> verify: one pipeline,
         // one synchronisation; the optimistic case needs a single pass
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
-        launch_class_insert(m->t, b, unit_base, m->unit_slot.p, m->unit_claim.p, pass > 0, m->stream);
-        if (device_exclusive_scan_u64(m->unit_claim.p, m->claim_scan.p, n_units, m->counters.p + CTR_CREATED,
-                                      m->scan_temp.p, scan_bytes, m->stream))
-            return fail(SKM_ERR_HIP, "prefix sum over the new classes failed: %s", hipGetErrorString(hipGetLastError()));
-        launch_class_commit(m->t, b, m->unit_slot.p, m->unit_claim.p, m->claim_scan.p,
-                            m->counters.p + CTR_CREATED, pass == 0, m->stream);
-        launch_class_verify(m->t, b, m->unit_slot.p, m->stream);
+        const int n_waves = two_waves && pass == 0 ? 2 : 1;
+        for (int wave = 0; wave < n_waves; ++wave) {
+            const int64_t w0 = n_waves == 1 || wave == 0 ? 0 : n_units / 4;
+            const int64_t w1 = n_waves == 1 || wave == 1 ? n_units : n_units / 4;
+            MapBatch part = b;                   // records [w0, w1) of the batch
+            part.rec_unit += w0; part.rec_key += w0; part.rec_tuple += w0;
+            part.n_units = w1 - w0;
+            launch_class_insert(m->t, part, unit_base, m->unit_slot.p + w0, m->unit_claim.p + w0, pass > 0, m->stream);
+            if (device_exclusive_scan_u64(m->unit_claim.p + w0, m->claim_scan.p + w0, w1 - w0, m->counters.p + CTR_CREATED,
+                                          m->scan_temp.p, scan_bytes, m->stream))
+                return fail(SKM_ERR_HIP, "prefix sum over the new classes failed: %s", hipGetErrorString(hipGetLastError()));
+            launch_class_commit(m->t, part, m->unit_slot.p + w0, m->unit_claim.p + w0, m->claim_scan.p + w0,
+                                m->counters.p + CTR_CREATED, pass == 0 && wave == 0, m->stream);
+            launch_class_verify(m->t, part, m->unit_slot.p + w0, m->stream);
+        }
         HIP_TRY(hipGetLastError());
         if (pass == 0) HIP_TRY(hipEventRecord(m->ev[3], m->stream));
         HIP_TRY(hipMemcpyAsync(m->pinned, m->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));

@@ -109,6 +109,12 @@ constexpr int INSERT_WIDTH = 4;
 #ifndef SKM_CLASS_EXPERIMENT
 #define SKM_CLASS_EXPERIMENT 0
 #endif
+#ifndef SKM_CLASS_AGG_BITS
+#define SKM_CLASS_AGG_BITS 11       // entries of the block's combining table (12 bytes of LDS each)
+#endif
+#ifndef SKM_CLASS_INSERT_BLOCKS
+#define SKM_CLASS_INSERT_BLOCKS 2048
+#endif
 
 __global__ void __launch_bounds__(256)
 class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot,
@@ -117,6 +123,16 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     // Unaligned units are tallied per block (LDS) and reach the device counter with one atomic
     // per block: atomics on one address serialise at ~10 ns apiece.
     __shared__ unsigned int s_unaligned;
+    // The count / first-seen updates of a block are combined in LDS before they go to the table: class
+    // sizes are skewed (the ten largest classes of a 10 M-pair batch hold 15 400 ... 4 100 units), a
+    // slot that is read by a probe and then hit by a device-scope atomic thousands of times is the
+    // launch's long pole (scripts/micro/atomic_layout.hip: 10 M read + add pairs take 0.45 ms spread
+    // evenly and 0.70 ms with 77 k of them on ten addresses), and a block meets a large class several
+    // times.  AGG entries, claimed once and never evicted: a record whose entry is taken by another
+    // slot updates the table directly.
+    constexpr int AGG = 1 << SKM_CLASS_AGG_BITS;
+    __shared__ unsigned int agg_slot[AGG], agg_count[AGG], agg_min[AGG];
+    for (int i = threadIdx.x; i < AGG; i += blockDim.x) { agg_slot[i] = 0; agg_count[i] = 0; agg_min[i] = 0xffffffffu; }
     if (threadIdx.x == 0) s_unaligned = 0;
     __syncthreads();
     unsigned int unaligned = 0;
@@ -170,8 +186,18 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
                         if (claimed) claim = (1ULL << 40) | (mine_at[k] >> 40);
                         const unsigned long long unit = (unsigned long long)(unit_base + unit_of[k]);
                         if (!(SKM_CLASS_EXPERIMENT & 1)) {
-                            atomicAdd(&t.slots[slot].count, 1ULL);
-                            if (claimed || seen > unit) atomicMin(&t.slots[slot].first_seen, unit);
+                            const bool lower = claimed || seen > unit;
+                            const unsigned int tag = (unsigned int)slot + 1u;
+                            const unsigned int h = (tag * 0x9E3779B1u) >> (32 - SKM_CLASS_AGG_BITS);
+                            unsigned int holder = (slot >> 31) ? ~0u : agg_slot[h];
+                            if (holder == 0) holder = atomicCAS(&agg_slot[h], 0u, tag);
+                            if (holder == 0 || holder == tag) {
+                                atomicAdd(&agg_count[h], 1u);
+                                if (lower) atomicMin(&agg_min[h], (unsigned int)unit_of[k]);
+                            } else {
+                                atomicAdd(&t.slots[slot].count, 1ULL);
+                                if (lower) atomicMin(&t.slots[slot].first_seen, unit);
+                            }
                         }
                         where = (int64_t)slot;
                         if (stored >= 0) {        // the class's tuple is in the arena: compare now
@@ -195,6 +221,13 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     if (!all_same) atomicExch(t.error, SKM_ERR_COLLISION);
     if (unaligned) atomicAdd(&s_unaligned, unaligned);
     __syncthreads();
+    for (int i = threadIdx.x; i < AGG; i += blockDim.x) {        // what the block combined
+        const unsigned int tag = agg_slot[i];
+        if (tag == 0) continue;
+        ClassSlot *slot = &t.slots[tag - 1u];
+        atomicAdd(&slot->count, (unsigned long long)agg_count[i]);
+        if (agg_min[i] != 0xffffffffu) atomicMin(&slot->first_seen, (unsigned long long)(unit_base + (int64_t)agg_min[i]));
+    }
     if (threadIdx.x == 0 && s_unaligned) atomicAdd(t.n_unaligned, (unsigned long long)s_unaligned);
     if (!retry_deferred && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(t.n_units, (unsigned long long)b.n_units);
@@ -407,8 +440,8 @@ void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_ba
                          hipStream_t stream)
 {
     if (b.n_units == 0) return;
-    // (2048 blocks: one same-address atomic per block for the unaligned tally)
-    hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units, 2048)), dim3(256), 0, stream, t, b,
+    // (one same-address atomic per block for the unaligned tally; a block combines what it meets)
+    hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units, SKM_CLASS_INSERT_BLOCKS)), dim3(256), 0, stream, t, b,
                        unit_base, unit_slot, unit_claim, retry_deferred);
 }
 
