@@ -1,6 +1,6 @@
 """Annotate a PMC summary of the map kernel (scripts/pmc_summary.py output) with the derived figures
 bench.py and DESIGN.md quote, and write it where bench.py looks for it.
-    python3 scripts/pmc_finish.py gpurun_out/pmc_<tag>.json profiles/r02_pmc_map.json"""
+    python3 scripts/pmc_finish.py gpurun_out/pmc_<tag>.json profiles/r03_pmc_map.json"""
 import json
 import sys
 

@@ -1,7 +1,9 @@
-"""The bench line the driver parses: the committed lines of this round (profiles/r02_bench*.json, written
-by `python bench.py [--config N]` on the MI355X box) carry every field of the contract, with the
-metric and the workloads BASELINE.json names, and their numbers hang together (value = units / time,
-roofline.frac = achieved / peak, achieved = algorithmic bytes / launch time)."""
+"""The bench line the driver parses: the committed lines (profiles/r03_bench.json, written by the default
+`python bench.py` on the MI355X box; profiles/r02_bench*.json from the round before) carry every field
+of the contract, with the metric and the workloads BASELINE.json names, and their numbers hang together
+(value = units / time, roofline.frac = achieved / peak, achieved = algorithmic bytes / launch time).
+The default line also carries the legs from outside the GPU (`e2e`) and a few timed steps of the other
+single-GPU configurations of BASELINE.json (`other_configs`)."""
 import json
 import os
 
@@ -20,7 +22,7 @@ def _line(name):
     return json.load(open(path))
 
 
-@pytest.mark.parametrize('name, config', [('r02_bench.json', 1), ('r02_bench_config3.json', 3),
+@pytest.mark.parametrize('name, config', [('r03_bench.json', 1), ('r02_bench.json', 1), ('r02_bench_config3.json', 3),
                                           ('r02_bench_config4.json', 4)])
 def test_committed_bench_lines_follow_the_contract(name, config):
     line = _line(name)
@@ -55,9 +57,37 @@ def test_committed_bench_lines_follow_the_contract(name, config):
 
 
 def test_default_line_reports_the_legs_from_outside_the_gpu():
-    line = _line('r02_bench.json')
+    line = _line('r03_bench.json')
     e2e = line['e2e']
-    assert e2e['pcie_inclusive']['value'] < line['value'] and e2e['pcie_inclusive']['unit'] == 'pairs/s'
-    assert e2e['fastq_inclusive']['value'] < e2e['pcie_inclusive']['value']
+    pcie, fastq = e2e['pcie_inclusive'], e2e['fastq_inclusive']
+    assert pcie['value'] < line['value'] and pcie['unit'] == 'pairs/s'
+    assert fastq['value'] < pcie['value']
     # the host-array leg cannot beat the link: its bytes over its time stay under PCIe 5 x16
-    assert e2e['pcie_inclusive']['GBps_over_pcie'] < 64.0
+    assert pcie['GBps_over_pcie'] < 64.0 and pcie['ascii']['GBps_over_pcie'] < 64.0
+    assert pcie['bytes_per_pair'] == 64.0                          # 2 x 100 bases as 2-bit code words
+    assert pcie['first_pass'] <= pcie['value'] and fastq['first_pass'] <= fastq['value']
+    # one pass over the text: every piece accepted as guessed, every read seen once
+    assert fastq['reader']['reparsed'] == 0 and fastq['reader']['units'] == line['config']['units_per_gpu']
+    assert fastq['reader']['reads'] == 2 * line['config']['units_per_gpu']
+    assert fastq['value'] > fastq['two_pass_ascii']['value'] and pcie['value'] > pcie['ascii']['value']
+
+
+def test_default_line_times_the_other_single_gpu_configs():
+    line = _line('r03_bench.json')
+    baseline = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    others = line['other_configs']
+    assert sorted(others) == ['configs[3]', 'configs[4]'] and len(baseline['configs']) > 4
+    for name, sub in others.items():
+        for field in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'workload', 'phase_ms', 'roofline'):
+            assert field in sub, (name, field)
+        assert sub['workload'].startswith(name) and sub['steps'] >= 3 and sub['warmup'] >= 1
+        assert sum(sub['phase_ms'].values()) <= sub['ms_per_step'] * 1.001
+        roofline = sub['roofline']
+        assert roofline['frac'] == pytest.approx(roofline['achieved'] / roofline['peak'], rel=1e-9)
+        assert roofline['achieved'] == pytest.approx(
+            roofline['algorithmic_bytes_per_launch'] / (roofline['launch_ms'] * 1e-3) / 1e9, rel=1e-6)
+    third, fourth = others['configs[3]'], others['configs[4]']
+    assert third['unit'] == 'reads/s' and '50000000 150bp single-end' in third['workload']
+    assert third['value'] == pytest.approx(50_000_000 / (third['ms_per_step'] * 1e-3), rel=1e-6)
+    assert fourth['unit'] == 'pairs/s' and fourth['bootstraps'] == 100 and fourth['bootstraps_per_s'] > 0
+    assert fourth['value'] == pytest.approx(20_000_000 / (fourth['ms_per_step'] * 1e-3), rel=1e-6)

@@ -973,7 +973,11 @@ def test_baseline_config4_properties(native_libs, t190k):
     tpm, iters, eff = infer.quantify_resident(result, return_iters=True, return_effective_lengths=True)
     class_count = result.export()[2].astype('f8')
     n = class_count.sum()
-    assert n == result.sizes()[3] - result.sizes()[2] and class_count.size > 800_000
+    assert n == result.sizes()[3] - result.sizes()[2]
+    # the table is a large one -- from the generator, not from a run: reads come from the transcripts of
+    # at least 300 bases, nearly all of them are drawn at this depth, and the isoforms of
+    # a gene differ by construction, so there are more classes than such transcripts
+    assert class_count.size > int((np.diff(tx_offsets) >= 300).sum())
     quant = infer._QuantHandle.from_map_result(result, len(ids))
     x0 = tpm / tpm.sum()
     out, counts, its = quant.bootstrap(n_boot, 99, x0, eff, want_counts=True)

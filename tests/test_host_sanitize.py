@@ -1,5 +1,6 @@
-"""libseekmer_host.so under AddressSanitizer + UBSan (CPU only): the FASTQ reader's two engines
-(ragged reads, CRLF, a batch carried across files, early exit with workers in flight, sharding),
+"""libseekmer_host.so under AddressSanitizer + UBSan (CPU only): the ASCII FASTQ reader's two engines
+(ragged reads, CRLF, a batch carried across files, early exit with workers in flight, sharding), the
+one-pass packed reader and skm_pack_reads over the same files (every parser variant of this CPU),
 the index builder on the reference's 3-transcript file and the synthetic generator + FASTQ writer
 must be clean."""
 import os
@@ -43,6 +44,35 @@ it = iter(common.NativeReadFeeder(paths, True, batch_units=50, threads=4))
 next(it); it.close()
 single = [b.count for b in common.NativeReadFeeder(paths[:1] + paths[2:3], False, batch_units=1000, threads=3)]
 assert sum(single) == 2278
+# the one-pass packed reader over the same files (N, lower case, CRLF, padded lines, a file without its
+# last newline): every parser variant this CPU has, tiny and large ranges, with and without workers --
+# the pieces hold the reads of the ASCII reader, packed as skm_pack_reads packs them
+flat_reads = [r for p in plain for r in p[2]]
+for variant in (0, 1, 2):
+    if _native.host().skm_pack_set_variant(variant) != 0:
+        continue
+    for threads, chunk in ((0, 97), (4, 1500), (3, 1 << 20)):
+        streams = [dict(), dict()]
+        for piece in common.PackedReadFeeder(paths, True, threads=threads, chunk_bytes=chunk, want_names=True):
+            keep = [r for r in streams[piece.stream] if r >= piece.first_read]
+            for r in keep:
+                del streams[piece.stream][r]
+            codes, lengths = piece.codes, piece.lengths
+            exc = dict(zip(piece.exceptions[0].tolist(), piece.exceptions[1]))
+            for r in range(piece.n_reads):
+                w = max(1, (int(lengths[r]) + 31) // 32)
+                streams[piece.stream][piece.first_read + r] = (codes[r, :w].tolist(), int(lengths[r]),
+                                                               exc[r][:w].tolist() if r in exc else None)
+        for u in range(2278):
+            for s in range(2):
+                read = flat_reads[2 * u + s]
+                want = common.PackedReads.from_ascii(np.frombuffer(read + b'\0', dtype=np.uint8),
+                                                     np.asarray([0, len(read)], dtype=np.int64), variant=variant)
+                w = max(1, (len(read) + 31) // 32)
+                wexc = want.exceptions
+                assert streams[s][u] == (want.codes[0, :w].tolist(), len(read),
+                                         wexc[1][0][:w].tolist() if wexc[0].size else None), (variant, threads, u, s)
+_native.host().skm_pack_set_variant(-1)
 ids, seqs = index_builder.read_transcripts(os.path.join(%(golden)r, 'human.cdna.21.with_extra.fa.gz'))
 index = index_builder.build(ids, seqs)
 assert index.contigs.size == 5
