@@ -113,7 +113,10 @@ def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units, paired, 
         # per-read malloc'd lists, which limits its thread scaling)
         'value': max(single, multi), 'unit': unit, 'cores': cores if multi > single else 1,
         'kind': 'port', 'single_thread_value': single, 'all_core_value': multi, 'host_cores': cores,
-        'sample': '%d %s of the same read set; 1 thread: oracle map %.2fs (%.0f %s) + classes/EM%s %.2fs '
+        'sample': 'the C port of the reference algorithm (oracle/) on THIS host -- not the reference\'s Cython build, whose '
+                  'ratio to the port could not be calibrated here (the reference is not importable in this image); the '
+                  'only reference-side figure is SURVEY.md 6: 132.9 k pairs/s at -j1 on an 8-vCPU Xeon.  '
+                  '%d %s of the same read set; 1 thread: oracle map %.2fs (%.0f %s) + classes/EM%s %.2fs '
                   '(%d EM steps); %d threads: map %.2fs (%.0f %s) + the same classes/EM'
                   % (sample_units, 'pairs' if paired else 'reads', t_map1, sample_units / t_map1, unit,
                      ' incl. %d bootstraps' % bootstraps if bootstraps else '', t_quant, iters, cores,
