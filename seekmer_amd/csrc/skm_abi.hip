@@ -196,6 +196,10 @@ struct skm_mapper {
     int packed_flush = 0;                     // callers waiting for everything mappable to be mapped
     bool packed_busy = false;
     int64_t packed_dropped = 0;               // reads that never got a mate
+    // HBM held by pieces that wait to be mapped; a pusher that is ahead of the GPU by more than
+    // PACKED_MAX_PENDING bytes waits (only while the worker has something to map: a caller that
+    // pushes one stream long before the other is never blocked on itself)
+    std::shared_ptr<std::atomic<int64_t>> packed_bytes = std::make_shared<std::atomic<int64_t>>(0);
     int vote[8] = {1, 1, 1, 1, 1, 1, 1, 0};   // quorum per action (start, lookup, merge, left, right, emit, scan)
 };
 
@@ -926,6 +930,7 @@ int run_job(skm_mapper *m, const skm_mapper::Job &job)
 // ---- packed pieces ----------------------------------------------------------------------
 constexpr int64_t PACKED_MIN_UNITS = 1 << 15;      // smaller runs wait for more (or for a flush)
 constexpr int64_t PACKED_MAX_UNITS = 1 << 21;      // one launch
+constexpr int64_t PACKED_MAX_PENDING = 8LL << 30;  // bytes of HBM that pieces may hold before a pusher waits
 
 // (q_mu held) the first run of units that every stream covers: [*lo, *hi), at most PACKED_MAX_UNITS
 bool packed_find_run(skm_mapper *m, int64_t *lo, int64_t *hi)
@@ -1260,10 +1265,23 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
     const size_t codes_bytes = round((size_t)n * cw * 8);
     const size_t len_bytes = uniform ? 0 : round((size_t)n * 4);
     const size_t exc_bytes = round((size_t)n_exc * 4), mask_bytes = round((size_t)n_exc * cw * 4);
+    const int64_t block_bytes = (int64_t)(codes_bytes + len_bytes + exc_bytes + mask_bytes + 256);
+    {
+        std::unique_lock<std::mutex> hold(m->q_mu);
+        m->done_cv.wait(hold, [&] {
+            if (m->packed_bytes->load() + block_bytes <= PACKED_MAX_PENDING || m->job_error != SKM_OK) return true;
+            int64_t lo, hi;
+            return !(m->packed_busy || packed_find_run(m, &lo, &hi));     // nothing the worker could free
+        });
+    }
     char *raw = nullptr;
-    HIP_TRY(pool_alloc((void **)&raw, codes_bytes + len_bytes + exc_bytes + mask_bytes + 256));
+    HIP_TRY(pool_alloc((void **)&raw, (size_t)block_bytes));
     skm_mapper::Piece held;
-    held.block = std::shared_ptr<char>(raw, [](char *q) { pool_free(q); });
+    {
+        std::shared_ptr<std::atomic<int64_t>> counter = m->packed_bytes;   // (outlives the mapper if a block does)
+        counter->fetch_add(block_bytes);
+        held.block = std::shared_ptr<char>(raw, [counter, block_bytes](char *q) { pool_free(q); counter->fetch_sub(block_bytes); });
+    }
     held.first = held.origin = piece->first_read;
     held.n = n;
     held.cw = cw;
