@@ -43,7 +43,11 @@ def run(index_path, output_path, fastq_paths, job_count, single_ended, debug, po
     _LOG.info('Mapping all reads')
     width = 1 if single_ended else 2
     groups = [tuple(fastq_paths[i:i + width]) for i in range(0, len(fastq_paths) - width + 1, width)]
-    feeders = [common.NativeReadFeeder(list(group), paired=not single_ended) for group in groups]
+    # (a cell's reads: plain files are parsed straight to the mapper's 2-bit codes by the thread that
+    # maps the cell -- one pass, a third of the bytes over PCIe; compressed ones through the ASCII reader)
+    feeders = [common.PackedReadFeeder(list(group), paired=not single_ended)
+               if common.PackedReadFeeder.eligible(group) else common.NativeReadFeeder(list(group), paired=not single_ended)
+               for group in groups]
     map_results = mapper.map_multiple_samples(index, feeders, job_count=job_count, debug=debug,
                                               device=device)
     _LOG.info('Mapped all reads.')

@@ -480,3 +480,27 @@ def test_sharded_feeders_partition_the_sample(native_libs, tmp_path, threads):
             assert [m[0] // 300 % world for m in mine] == [rank] * len(mine)
             parts += mine
         assert sorted(parts) == whole
+
+
+def test_infer_chooses_its_reader(tmp_path):
+    """infer._feeder: plain files on one rank go through the one-pass packed reader; compressed input,
+    -m (readmap.txt in the reference's batches) and a rank's share of a sample keep the ASCII reader."""
+    import gzip
+    from seekmer_amd import common, infer
+    plain = [tmp_path / 'a_1.fastq', tmp_path / 'a_2.fastq']
+    for path in plain:
+        path.write_bytes(b'@r\nACGT\n+\nIIII\n')
+    packed = tmp_path / 'b_1.fastq.gz'
+    with gzip.open(packed, 'wb') as f:
+        f.write(b'@r\nACGT\n+\nIIII\n')
+    chosen = infer._feeder(plain, True, None, None, False)
+    assert isinstance(chosen, common.PackedReadFeeder) and chosen.paired and 1 <= chosen.threads <= 16
+    assert isinstance(infer._feeder(plain, True, 3, (0, 1), False), common.PackedReadFeeder)
+    assert isinstance(infer._feeder(plain, True, None, None, True), common.NativeReadFeeder)       # -m
+    assert isinstance(infer._feeder(plain, True, None, (1, 2), False), common.NativeReadFeeder)    # a rank of two
+    assert isinstance(infer._feeder([packed, plain[1]], True, None, None, False), common.NativeReadFeeder)
+    assert isinstance(infer._feeder(plain, True, 0, None, False), common.NativeReadFeeder)         # --parse-threads 0
+    assert common.PackedReadFeeder.eligible(plain) and not common.PackedReadFeeder.eligible([packed])
+    # the reader's pieces of this tiny sample: one read per stream
+    pieces = [(p.stream, p.first_read, p.n_reads, p.lengths.tolist()) for p in chosen]
+    assert sorted(pieces) == [(0, 0, 1, [4]), (1, 0, 1, [4])]
