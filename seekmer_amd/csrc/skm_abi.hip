@@ -134,8 +134,6 @@ struct skm_mapper {
     DBuf<Coord> unit_anchor;
     DBuf<int64_t> unit_slot;
     DBuf<unsigned long long> rec_tuple;
-    DBuf<unsigned long long> unit_claim, claim_scan;
-    DBuf<char> scan_temp;
     unsigned long long *pinned = nullptr;   // host-pinned readback words
     DBuf<uint64_t> rec_key;
     bool keep_spans = false, last_spans = false;   // spans wanted / written by the last batch
@@ -585,7 +583,7 @@ extern "C" int skm_index_layout(const skm_index *ix, int64_t layout[8])
 namespace {
 
 constexpr int CTR_ARENA = 0, CTR_CLASSES = 1, CTR_UNALIGNED = 2, CTR_UNITS = 3, CTR_LISTED = 4,
-              CTR_DEFERRED = 5, CTR_CREATED = 6, CTR_FLD = 8;
+              CTR_DEFERRED = 5, CTR_COMMITTED = 6, CTR_FLD = 8;
 constexpr int CTR_WORDS = 8 + MAX_FRAGMENT_LENGTH;
 constexpr int BC_IDS = 0, BC_FLD = 8, BC_STATS = 2048, BC_WORDS = 2096;
 
@@ -604,6 +602,7 @@ void bind_table(skm_mapper *m, uint64_t n_slots)
     m->t.class_list_capacity = (int64_t)m->class_list.cap;
     m->t.n_listed = m->counters.p + CTR_LISTED;
     m->t.n_deferred = m->counters.p + CTR_DEFERRED;
+    m->t.arena_committed = m->counters.p + CTR_COMMITTED;
     m->t.error = m->error.p;
 }
 
@@ -715,8 +714,6 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(m->rec_unit.ensure(n_units));
     SKM_TRY(m->rec_tuple.ensure(n_units));
     SKM_TRY(m->unit_slot.ensure(n_units));
-    SKM_TRY(m->unit_claim.ensure(n_units));
-    SKM_TRY(m->claim_scan.ensure(n_units));
     SKM_TRY(m->rec_key.ensure(n_units));
 
     SKM_TRY(m->batch_ctl.ensure(BC_WORDS));
@@ -791,30 +788,35 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(table_reserve(m, n_units));
     SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)ids + 1024), true, m->stream));
     bind_table(m, m->t.slot_mask + 1);
-    const size_t scan_bytes = device_scan_u64_temp_bytes(n_units);
-    SKM_TRY(m->scan_temp.ensure(scan_bytes + 16));
     // A large batch on an empty table goes in two waves of records: once the classes of the first
     // quarter are committed, most records of the rest land on a committed class and are verified
     // inside class_insert (the slot's tuple word came with the probe); class_verify's second random
     // pass over the table is left with the first wave and the records of classes new in the second.
     const bool two_waves = m->host_classes == 0 && n_units >= (1 << 21);
     for (int pass = 0;; ++pass) {
-        // insert -> prefix sum over the creators -> commit -> totals -> verify: one pipeline,
-        // one synchronisation; the optimistic case needs a single pass
+        // insert (with the commit of the new classes) -> totals -> verify: one pipeline, one
+        // synchronisation; the optimistic case needs a single pass
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
-        const int n_waves = two_waves && pass == 0 ? 2 : 1;
+        // (wave borders in sixteenths of the batch; SKM_CLASS_WAVES="2,8" etc. is a tuning aid)
+        int cuts[8] = {4, 16, 16, 16, 16, 16, 16, 16};
+        int n_waves = two_waves && pass == 0 ? 2 : 1;
+        if (n_waves > 1)
+            if (const char *e = getenv("SKM_CLASS_WAVES")) {
+                n_waves = 0;
+                for (const char *c = e; *c && n_waves < 7;) {
+                    cuts[n_waves++] = atoi(c);
+                    while (*c && *c != ',') ++c;
+                    if (*c == ',') ++c;
+                }
+                if (n_waves == 0 || cuts[n_waves - 1] < 16) cuts[n_waves++] = 16;
+            }
         for (int wave = 0; wave < n_waves; ++wave) {
-            const int64_t w0 = n_waves == 1 || wave == 0 ? 0 : n_units / 4;
-            const int64_t w1 = n_waves == 1 || wave == 1 ? n_units : n_units / 4;
+            const int64_t w0 = n_waves == 1 || wave == 0 ? 0 : n_units * cuts[wave - 1] / 16;
+            const int64_t w1 = n_waves == 1 ? n_units : n_units * cuts[wave] / 16;
             MapBatch part = b;                   // records [w0, w1) of the batch
             part.rec_unit += w0; part.rec_key += w0; part.rec_tuple += w0;
             part.n_units = w1 - w0;
-            launch_class_insert(m->t, part, unit_base, m->unit_slot.p + w0, m->unit_claim.p + w0, pass > 0, m->stream);
-            if (device_exclusive_scan_u64(m->unit_claim.p + w0, m->claim_scan.p + w0, w1 - w0, m->counters.p + CTR_CREATED,
-                                          m->scan_temp.p, scan_bytes, m->stream))
-                return fail(SKM_ERR_HIP, "prefix sum over the new classes failed: %s", hipGetErrorString(hipGetLastError()));
-            launch_class_commit(m->t, part, m->unit_slot.p + w0, m->unit_claim.p + w0, m->claim_scan.p + w0,
-                                m->counters.p + CTR_CREATED, pass == 0 && wave == 0, m->stream);
+            launch_class_insert(m->t, part, unit_base, m->unit_slot.p + w0, pass > 0, pass == 0 && wave == 0, m->stream);
             launch_class_verify(m->t, part, m->unit_slot.p + w0, m->stream);
         }
         HIP_TRY(hipGetLastError());
@@ -898,7 +900,6 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->unit_slot.release(); m->rec_key.release(); m->unit_entries.release(); m->batch_ctl.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
     if (m->pinned) (void)hipHostFree(m->pinned);
-    m->unit_claim.release(); m->claim_scan.release(); m->scan_temp.release();
     pool_stream_release(m->stream);
     delete m;
     return SKM_OK;

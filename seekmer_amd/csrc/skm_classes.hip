@@ -4,20 +4,24 @@
 // in MapResult.summarize (mapper.py:85-92).
 //
 // Open-addressing table keyed by a 64-bit tag of the tuple.  A batch is
-// counted in launches, so that no lane ever spins on another lane:
+// counted in launches, so that no lane ever spins on another lane and nothing
+// one lane stores is read by another in the same launch:
 //   insert  -- claim or find the slot by tag (atomicCAS), count++ and
-//              first_seen = min(global unit index) (integer atomics); the lane
-//              whose CAS created the class is its creator
-//   (scan)  -- device-wide exclusive prefix sum over the creators gives each new
-//              class its registry index and arena offset: no allocation atomics
-//   commit  -- creators store their tuple in the arena and the slot in the
-//              dense class registry
-//   verify  -- every unit compares its FULL tuple with the stored one; a
-//              mismatch is a 64-bit tag collision and raises
-//              SKM_ERR_COLLISION, so counts are exact or the call fails --
-//              never silently merged
+//              first_seen = min(global unit index) (integer atomics, combined per
+//              block in LDS first); the lane whose CAS created the class is its
+//              creator and commits it on the spot: the block's creators take
+//              their registry entries and arena space with ONE atomicAdd per
+//              counter and block iteration, store their tuples and the slots'
+//              tuple words.  A record that finds a class committed BEFORE this
+//              launch compares its full tuple with the stored one at once
+//   verify  -- the records that met a class created in the same launch compare
+//              their FULL tuple with the stored one; a mismatch is a 64-bit tag
+//              collision and raises SKM_ERR_COLLISION, so counts are exact or
+//              the call fails -- never silently merged
 // The launch boundary orders the tuple stores before the compares; within a
-// launch only device-scope atomics touch shared words.
+// launch only device-scope atomics touch shared words (a tuple word that a
+// finder happens to see already set by a creator of the same launch is treated
+// as not yet there: its arena offset is not below the launch's starting cursor).
 #include "skm_kernels.h"
 #include "../../include/seekmer_hip.h"
 
@@ -117,9 +121,13 @@ constexpr int INSERT_WIDTH = 4;
 #endif
 
 __global__ void __launch_bounds__(256)
-class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot,
-                    unsigned long long *unit_claim, bool retry_deferred)
+class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_slot, bool retry_deferred)
 {
+    // tuples stored below this arena offset were committed by an earlier launch (class_totals_kernel
+    // publishes the cursor between launches): only those are compared on the spot
+    const long long committed = (long long)*t.arena_committed;
+    __shared__ unsigned int s_new_classes[4], s_new_ids[4];
+    __shared__ unsigned long long s_base[2];
     // Unaligned units are tallied per block (LDS) and reach the device counter with one atomic
     // per block: atomics on one address serialise at ~10 ns apiece.
     __shared__ unsigned int s_unaligned;
@@ -139,8 +147,14 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     bool all_same = true;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // (u walks the batch's RECORDS, skm_kernels.h: MapBatch; unit_slot / unit_claim are by record)
-    for (int64_t u0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u0 < b.n_units; u0 += INSERT_WIDTH * stride) {
+    // (every lane of a block runs the same number of iterations: the commit of an iteration is a
+    // block-wide step)
+    for (int64_t ub = blockIdx.x * (int64_t)blockDim.x; ub < b.n_units; ub += INSERT_WIDTH * stride) {
+        const int64_t u0 = ub + threadIdx.x;
         unsigned long long key[INSERT_WIDTH], mine_at[INSERT_WIDTH];
+        int64_t made_slot[INSERT_WIDTH];              // slot of a class this lane created in this iteration, or -1
+#pragma unroll
+        for (int k = 0; k < INSERT_WIDTH; ++k) made_slot[k] = -1;
         ulonglong2 head[INSERT_WIDTH];
         long long tuple_word[INSERT_WIDTH];
         int32_t unit_of[INSERT_WIDTH];
@@ -164,9 +178,8 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
         for (int k = 0; k < INSERT_WIDTH; ++k) {
             const int64_t u = u0 + k * stride;
             if (u >= b.n_units) continue;
-            // every record leaves with ONE store to unit_slot (new ones) and ONE to unit_claim, issued
-            // at the end: on gfx9 a store issued before the loads would have to drain in front of them
-            unsigned long long claim = 0;
+            // every record leaves with ONE store to unit_slot, issued at the end: on gfx9 a store issued
+            // before the loads would have to drain in front of them
             int64_t where = -1;
             if (live[k]) {
                 if (key[k] == 0) {                // empty tuple = unaligned, mapper.py:87
@@ -181,9 +194,7 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
                         atomicAdd(t.n_deferred, 1ULL);
                         where = -2;
                     } else {
-                        // the creator of a class stores its tuple later (class_commit_kernel): one
-                        // class (bits 40+) and n arena ids (bits 0-39), placed by a device-wide scan
-                        if (claimed) claim = (1ULL << 40) | (mine_at[k] >> 40);
+                        if (claimed) made_slot[k] = (int64_t)slot;      // committed below, with the block's others
                         const unsigned long long unit = (unsigned long long)(unit_base + unit_of[k]);
                         if (!(SKM_CLASS_EXPERIMENT & 1)) {
                             const bool lower = claimed || seen > unit;
@@ -199,8 +210,8 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
                                 if (lower) atomicMin(&t.slots[slot].first_seen, unit);
                             }
                         }
-                        where = (int64_t)slot;
-                        if (stored >= 0) {        // the class's tuple is in the arena: compare now
+                        where = claimed ? -1 : (int64_t)slot;
+                        if (stored >= 0 && tuple_offset(stored) < committed) {   // in the arena since an earlier launch: compare now
                             const int n = (int)(mine_at[k] >> 40);
                             bool same = tuple_len(stored) == n;
                             if (same) {
@@ -215,8 +226,54 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
                 }
                 unit_slot[u] = where;
             }
-            unit_claim[u] = claim;                // (a record counted in an earlier pass: only its claim is cleared)
         }
+        // ---- the block's new classes of this iteration: registry entries and arena space with one
+        // atomicAdd per counter, then every creator stores its tuple
+        unsigned int my_classes = 0, my_ids = 0;
+#pragma unroll
+        for (int k = 0; k < INSERT_WIDTH; ++k)
+            if (made_slot[k] >= 0) { ++my_classes; my_ids += (unsigned int)(mine_at[k] >> 40); }
+        unsigned int before_classes = my_classes, before_ids = my_ids;       // inclusive scan over the wave
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int c = __shfl_up(before_classes, d, 64), i = __shfl_up(before_ids, d, 64);
+            if (lane >= d) { before_classes += c; before_ids += i; }
+        }
+        if (lane == 63) { s_new_classes[wave] = before_classes; s_new_ids[wave] = before_ids; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int classes = s_new_classes[0] + s_new_classes[1] + s_new_classes[2] + s_new_classes[3];
+            const unsigned int ids = s_new_ids[0] + s_new_ids[1] + s_new_ids[2] + s_new_ids[3];
+            s_base[0] = s_base[1] = 0;
+            if (classes) {
+                s_base[0] = atomicAdd(t.n_listed, (unsigned long long)classes);
+                s_base[1] = atomicAdd(t.arena_cursor, (unsigned long long)ids);
+                atomicAdd(t.n_classes, (unsigned long long)classes);
+            }
+        }
+        __syncthreads();
+        if (my_classes) {
+            long long registry = (long long)s_base[0] + (before_classes - my_classes);
+            long long at = (long long)s_base[1] + (before_ids - my_ids);
+            for (int w = 0; w < wave; ++w) { registry += s_new_classes[w]; at += s_new_ids[w]; }
+#pragma unroll
+            for (int k = 0; k < INSERT_WIDTH; ++k) {
+                if (made_slot[k] < 0) continue;
+                const int n = (int)(mine_at[k] >> 40);
+                if (at + n > t.arena_capacity || registry >= t.class_list_capacity) {
+                    atomicExch(t.error, SKM_ERR_STATE);
+                } else {
+                    const int32_t *entries = b.unit_entries + (mine_at[k] & ((1ULL << 40) - 1));
+                    for (int i = 0; i < n; ++i) t.arena[at + i] = (int32_t)unsigned_id(entries[i]);
+                    t.slots[made_slot[k]].tuple = tuple_pack(at, n);
+                    t.class_list[registry] = made_slot[k];
+                }
+                at += n;
+                ++registry;
+            }
+        }
+        __syncthreads();                              // (s_new_* are rewritten by the next iteration)
     }
     if (!all_same) atomicExch(t.error, SKM_ERR_COLLISION);
     if (unaligned) atomicAdd(&s_unaligned, unaligned);
@@ -233,47 +290,17 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
         atomicAdd(t.n_units, (unsigned long long)b.n_units);
 }
 
-// creators copy their tuple to the arena position the prefix sum assigned,
-// counted from the table's current totals (device counters; stable during this launch)
+// between the launches of a batch: what has been committed so far is published for the next
+// launch's on-the-spot compares (and, once per batch, the batch histogram is merged:
+// merge_fragment_lengths, mapper.py:106-115)
 __global__ void __launch_bounds__(256)
-class_commit_kernel(ClassTable t, MapBatch b, const int64_t *unit_slot,
-                    const unsigned long long *unit_claim, const unsigned long long *claim_scan)
+class_totals_kernel(ClassTable t, const unsigned long long *batch_fld)
 {
-    const long long class_base = (long long)*t.n_listed;
-    const long long arena_base = (long long)*t.arena_cursor;
-    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u < b.n_units;
-         u += (int64_t)gridDim.x * blockDim.x) {
-        if (unit_claim[u] == 0) continue;
-        const int n = (int)(unit_claim[u] & ((1ULL << 40) - 1));
-        const long long k = class_base + (long long)(claim_scan[u] >> 40);
-        const long long off = arena_base + (long long)(claim_scan[u] & ((1ULL << 40) - 1));
-        if (off + n > t.arena_capacity || k >= t.class_list_capacity) {
-            atomicExch(t.error, SKM_ERR_STATE);
-            continue;
-        }
-        const int64_t slot = unit_slot[u];
-        const int32_t *entries = b.unit_entries + (b.rec_tuple[u] & ((1ULL << 40) - 1));
-        for (int i = 0; i < n; ++i) t.arena[off + i] = (int32_t)unsigned_id(entries[i]);
-        t.slots[slot].tuple = tuple_pack(off, n);
-        t.class_list[k] = slot;
-    }
-}
-
-// after the commit: the table's totals move on by what was created (and, once per
-// batch, the batch histogram is merged: merge_fragment_lengths, mapper.py:106-115)
-__global__ void __launch_bounds__(256)
-class_totals_kernel(ClassTable t, MapBatch b, const unsigned long long *created, bool merge_fld)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned long long c = *created;
-        *t.arena_cursor += c & ((1ULL << 40) - 1);
-        *t.n_listed += c >> 40;
-        *t.n_classes += c >> 40;
-    }
-    if (merge_fld)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *t.arena_committed = *t.arena_cursor;
+    if (batch_fld)
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < MAX_FRAGMENT_LENGTH;
              i += gridDim.x * blockDim.x)
-            t.global_fld[i] += b.fld[i];
+            t.global_fld[i] += batch_fld[i];
 }
 
 __global__ void __launch_bounds__(256)
@@ -436,23 +463,13 @@ void launch_class_init(const ClassTable &t, hipStream_t stream)
 }
 
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                         int64_t *unit_slot, unsigned long long *unit_claim, bool retry_deferred,
-                         hipStream_t stream)
+                         int64_t *unit_slot, bool retry_deferred, bool merge_fld, hipStream_t stream)
 {
     if (b.n_units == 0) return;
     // (one same-address atomic per block for the unaligned tally; a block combines what it meets)
     hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units, SKM_CLASS_INSERT_BLOCKS)), dim3(256), 0, stream, t, b,
-                       unit_base, unit_slot, unit_claim, retry_deferred);
-}
-
-void launch_class_commit(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
-                         const unsigned long long *unit_claim, const unsigned long long *claim_scan,
-                         const unsigned long long *created, bool merge_fld, hipStream_t stream)
-{
-    if (b.n_units == 0) return;
-    hipLaunchKernelGGL(class_commit_kernel, dim3(grid_for(b.n_units)), dim3(256), 0, stream, t, b,
-                       unit_slot, unit_claim, claim_scan);
-    hipLaunchKernelGGL(class_totals_kernel, dim3(8), dim3(256), 0, stream, t, b, created, merge_fld);
+                       unit_base, unit_slot, retry_deferred);
+    hipLaunchKernelGGL(class_totals_kernel, dim3(8), dim3(256), 0, stream, t, merge_fld ? b.fld : nullptr);
 }
 
 void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
@@ -492,6 +509,7 @@ void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *c
     if (n_classes == 0) return;
     hipLaunchKernelGGL(class_merge_kernel, dim3(grid_for(n_classes)), dim3(256), 0, stream, t,
                        n_classes, class_offsets, class_targets, class_counts, first_seen);
+    hipLaunchKernelGGL(class_totals_kernel, dim3(1), dim3(64), 0, stream, t, (const unsigned long long *)nullptr);
 }
 
 }  // namespace skm

@@ -101,22 +101,15 @@ struct ClassTable {
     int64_t class_list_capacity;
     unsigned long long *n_listed;
     unsigned long long *n_deferred;   // units whose probe ran past PROBE_LIMIT (table too full)
+    unsigned long long *arena_committed;   // arena cursor as of the last finished launch
     int *error;                   // SKM_ERR_* raised by a kernel
 };
 constexpr int CLASS_PROBE_LIMIT = 128;
-// (the class kernels walk the batch record by record; unit_slot / unit_claim / claim_scan are
-// indexed by record)
+// (the class kernels walk the batch record by record; unit_slot is indexed by record.)  insert:
+// find-or-create + count + commit of the new classes + on-the-spot compare with classes of earlier
+// launches, then the totals step (publishes the arena cursor; merge_fld: the batch histogram once)
 void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_base,
-                         int64_t *unit_slot, unsigned long long *unit_claim, bool retry_deferred,
-                         hipStream_t stream);
-void launch_class_commit(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
-                         const unsigned long long *unit_claim, const unsigned long long *claim_scan,
-                         const unsigned long long *created, bool merge_fld, hipStream_t stream);
-// exclusive prefix sum of n u64 values (hipCUB), asynchronous; *total_device (HBM) = sum of all
-size_t device_scan_u64_temp_bytes(int64_t n);
-int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
-                              unsigned long long *total_device, void *temp, size_t temp_bytes,
-                              hipStream_t stream);
+                         int64_t *unit_slot, bool retry_deferred, bool merge_fld, hipStream_t stream);
 void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
                          hipStream_t stream);
 void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,

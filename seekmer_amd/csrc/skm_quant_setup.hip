@@ -174,13 +174,6 @@ copy_tuples_kernel(const int32_t *perm, int64_t n, const int64_t *arena_off, con
     }
 }
 
-__global__ void __launch_bounds__(64)
-sum_last_kernel(const unsigned long long *in, const unsigned long long *scan, int64_t n,
-                unsigned long long *total)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) *total = in[n - 1] + scan[n - 1];
-}
-
 __global__ void __launch_bounds__(256)
 set_last_offset_kernel(int64_t *offsets, const int64_t *lens, int64_t n)
 {
@@ -304,27 +297,6 @@ int sort_pairs(Scratch &scratch, const K *keys_in, K *keys_out, const int32_t *v
 }
 
 }  // namespace
-
-size_t device_scan_u64_temp_bytes(int64_t n)
-{
-    size_t bytes = 0;
-    unsigned long long *p = nullptr;
-    if (n <= 0 || n >= (1LL << 31)) return 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, p, p, (int)n, nullptr) != hipSuccess) return 0;
-    return bytes;
-}
-
-// out = exclusive prefix sum of in[0..n); *total_device (HBM) = sum of all; asynchronous
-int device_exclusive_scan_u64(const unsigned long long *in, unsigned long long *out, int64_t n,
-                              unsigned long long *total_device, void *temp, size_t temp_bytes,
-                              hipStream_t stream)
-{
-    if (n == 0) { QB_TRY(hipMemsetAsync(total_device, 0, 8, stream)); return 0; }
-    if (n >= (1LL << 31)) return -2;
-    QB_TRY(hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, stream));
-    hipLaunchKernelGGL(sum_last_kernel, dim3(1), dim3(64), 0, stream, in, out, n, total_device);
-    return 0;
-}
 
 int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids)
 {
