@@ -162,8 +162,9 @@ typedef struct skm_packed_reads {
  * every run of units that its streams cover (single-ended: stream 0 alone; paired: unit u = read u
  * of stream 0 + read u of stream 1).  A piece whose first_read lies below the end of what its stream
  * holds replaces the reads from there on.  skm_mapper_sync -- and every call that reads the table
- * -- first maps what is still waiting; reads left without a mate at that point are dropped
- * (zip(file1, file2): seekmer/common.py:180-197).  Class order does not depend on how the
+ * -- first maps every unit whose reads have all arrived; reads still without a mate are not part
+ * of any result (zip(file1, file2): seekmer/common.py:180-197) and wait in HBM until their mates
+ * come or the handle is reset, cleared or destroyed.  Class order does not depend on how the
  * pieces were cut or when they arrived: first-seen values are unit numbers. */
 int skm_mapper_push_packed(skm_mapper *mapper, const skm_packed_reads *piece, int paired);
 /* Drain a source of pieces (skm_fastq_packed_next with its reader as context) into the mapper

@@ -1052,11 +1052,10 @@ void worker_main(skm_mapper *m)
                     packed = true;
                     break;
                 }
-                if ((m->packed_flush || m->stop) && (!m->pending[0].empty() || !m->pending[1].empty())) {
+                if (m->stop) {                  // stop requested and nothing left to map
                     packed_drop_all(m);
-                    m->done_cv.notify_all();
+                    return;
                 }
-                if (m->stop) return;            // stop requested and nothing left
                 m->q_cv.wait(hold);
             }
             if (!packed) {
@@ -1133,8 +1132,9 @@ void worker_main(skm_mapper *m)
 }
 
 // wait until every queued batch up to `ticket` has been mapped (0 = all of them AND every packed
-// read that has a mate: what is left without one is dropped); reports (and, with `consume`,
-// forgets) the first failure among them
+// read whose mate has arrived; reads still without one keep waiting in HBM -- another thread may be
+// about to push their mates -- until skm_mapper_reset / _clear / _destroy); reports (and, with
+// `consume`, forgets) the first failure among them
 int wait_jobs(skm_mapper *m, uint64_t ticket, bool consume)
 {
     std::unique_lock<std::mutex> hold(m->q_mu);
@@ -1143,7 +1143,10 @@ int wait_jobs(skm_mapper *m, uint64_t ticket, bool consume)
     if (ticket == 0 && (m->packed_busy || !m->pending[0].empty() || !m->pending[1].empty())) {
         m->packed_flush++;
         m->q_cv.notify_all();
-        m->done_cv.wait(hold, [&] { return !m->packed_busy && m->pending[0].empty() && m->pending[1].empty(); });
+        m->done_cv.wait(hold, [&] {
+            int64_t lo, hi;
+            return !m->packed_busy && (m->job_error != SKM_OK || !packed_find_run(m, &lo, &hi));
+        });
         m->packed_flush--;
     }
     if (m->job_error != SKM_OK && m->job_error_ticket <= upto) {
@@ -1555,6 +1558,10 @@ extern "C" int skm_mapper_clear(skm_mapper *m)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
     (void)wait_jobs(m, 0, true);            // (a failed queued batch is forgotten with the table)
+    {
+        std::lock_guard<std::mutex> hold(m->q_mu);      // (and packed reads that never got a mate)
+        packed_drop_all(m);
+    }
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     // MapResult.clear only clears the counter (mapper.py:143-145): the FLD stays
@@ -1570,6 +1577,10 @@ extern "C" int skm_mapper_reset(skm_mapper *m)
 {
     if (!m) return fail(SKM_ERR_ARG, "NULL mapper");
     (void)wait_jobs(m, 0, true);            // (a failed queued batch is forgotten with the table)
+    {
+        std::lock_guard<std::mutex> hold(m->q_mu);      // (and packed reads that never got a mate)
+        packed_drop_all(m);
+    }
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     SKM_TRY(table_reset(m, m->t.slot_mask + 1));

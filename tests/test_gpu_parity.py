@@ -1268,7 +1268,25 @@ def test_packed_reads_give_the_same_tables(oracle, native_libs, chr21, chr21_ora
         for k in order:
             rm.push_packed(pieces[k])
         same(one)
-    # mate 1 has reads without a mate at the end: dropped (zip(file1, file2))
+    # three threads push their shares of the pieces and each syncs when it is done, while the others
+    # are still pushing: a sync maps what has both mates and leaves the rest waiting for theirs
+    import threading
+    one.reset()
+    order = rng.permutation(len(pieces)).tolist()
+
+    def push_share(share):
+        pusher = mapper.ReadMapper(index, one)
+        for k in share:
+            pusher.push_packed(pieces[k])
+        one.sync()
+
+    threads = [threading.Thread(target=push_share, args=(order[t::3],)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    same(one)
+    # mate 1 has reads without a mate at the end: they are in no result (zip(file1, file2))
     if paired:
         one.reset()
         rm.push_packed(streams[0])
