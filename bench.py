@@ -342,10 +342,11 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
     def quantify_ranks(map_result):
         # fragment lengths (RCCL all-reduce over the ranks) -> effective lengths -> start vector -> EM
         # -> TPM: one native call on the resident class table
-        tpm, iters, eff = infer.quantify_resident(map_result, comm=comm if comm else None, return_iters=True,
-                                                  return_effective_lengths=True)
-        state['iters'], state['eff'] = iters, eff
-        return tpm
+        out = infer.quantify_resident(map_result, comm=comm if comm else None, return_iters=True,
+                                      return_effective_lengths=bool(bootstraps))    # (the `-b N` loop starts from them)
+        state['iters'] = out[1]
+        state['eff'] = out[2] if bootstraps else None
+        return out[0]
 
     def step():
         t = time.perf_counter()

@@ -144,6 +144,11 @@ struct skm_mapper {
     int64_t first_seen_bound = 0;     // every first_seen in the table is below this
     int64_t last_units = 0, last_ids = 0;
     int64_t host_classes = 0, host_arena_used = 0;
+    // the table's unit totals as the last mapped batch read them back (valid: nothing else -- a merge
+    // of a foreign table -- has changed the device counters since): spares skm_quant_infer a
+    // synchronous read of two words
+    bool host_totals_valid = false;
+    unsigned long long host_units = 0, host_unaligned = 0;
     int want_stats = 0;               // 0 production, 1 counting build, 2 census build
     double t_pack_ns = 0, t_map_ns = 0, t_class_ns = 0, batches = 0;
     double t_em_ns = 0, em_iters = 0;          // skm_quant_infer calls on this mapper
@@ -620,6 +625,8 @@ int table_reset(skm_mapper *m, uint64_t n_slots)
     HIP_TRY(hipGetLastError());
     m->host_classes = 0;
     m->host_arena_used = 0;
+    m->host_units = m->host_unaligned = 0;
+    m->host_totals_valid = true;
     m->units_done = 0;
     m->first_seen_bound = 0;
     return SKM_OK;
@@ -831,6 +838,9 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         if (err) return fail(err, "class table kernel reported error %d", err);
         m->host_arena_used = (int64_t)m->pinned[CTR_ARENA];
         m->host_classes = (int64_t)m->pinned[CTR_CLASSES];
+        m->host_units = m->pinned[CTR_UNITS];
+        m->host_unaligned = m->pinned[CTR_UNALIGNED];
+        m->host_totals_valid = true;
         if (m->pinned[CTR_LISTED] != m->pinned[CTR_CLASSES])
             return fail(SKM_ERR_STATE, "class registry out of step (%llu listed, %llu classes)",
                         m->pinned[CTR_LISTED], m->pinned[CTR_CLASSES]);
@@ -1509,6 +1519,7 @@ extern "C" int skm_mapper_merge(skm_mapper *m, int64_t n_classes, const int64_t 
         return fail(SKM_ERR_ARG, "NULL class arrays");
     SKM_TRY(wait_jobs(m, 0, false));           // queued host batches first
     std::lock_guard<std::mutex> lock(m->mu);
+    m->host_totals_valid = false;             // (the totals change on the device below)
     SKM_TRY(set_device(m->ix->device));
     std::vector<unsigned long long> add(CTR_WORDS, 0);
     int64_t units = unaligned;
@@ -1584,7 +1595,7 @@ extern "C" int skm_mapper_reset(skm_mapper *m)
     std::lock_guard<std::mutex> lock(m->mu);
     SKM_TRY(set_device(m->ix->device));
     SKM_TRY(table_reset(m, m->t.slot_mask + 1));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));         // (readers of the table use streams of their own)
     m->last_units = 0;
     m->last_ids = 0;
     return SKM_OK;
@@ -1974,8 +1985,9 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         SKM_TRY(fld.ensure(MAX_FRAGMENT_LENGTH + 1));
         SKM_TRY(sums.ensure(n_blocks + 2));
         double *const total = sums.p + n_blocks;          // [0] sum, [1] sum / divisor
-        unsigned long long ctr[4];
-        HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));   // (mapper stream is idle)
+        unsigned long long ctr[4] = {0, 0, m->host_unaligned, m->host_units};
+        if (!m->host_totals_valid)
+            HIP_TRY(hipMemcpy(ctr, m->counters.p, sizeof(ctr), hipMemcpyDeviceToHost));   // (mapper stream is idle)
         unsigned long long aligned = ctr[CTR_UNITS] - ctr[CTR_UNALIGNED];
         HIP_TRY(hipMemcpyAsync(fld.p, m->counters.p + CTR_FLD, MAX_FRAGMENT_LENGTH * 8,
                                hipMemcpyDeviceToDevice, q->stream));
@@ -1997,11 +2009,13 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         q->n_total = (double)aligned;
         HIP_TRY(hipMemcpyAsync(q->x1.p, lengths, n_tx * 8, hipMemcpyHostToDevice, q->stream));
         launch_effective_lengths(fld.p, q->x1.p, n_tx, q->eff_len.p, q->stream);
-        if (effective_lengths)
-            HIP_TRY(hipMemcpyAsync(effective_lengths, q->eff_len.p, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
+        // (the effective lengths go home at the end, with the TPM: a copy to pageable memory holds the
+        // host up, and the kernels that follow are not launched meanwhile)
         // quantify(): no class -> zeros (infer.py:106-107); over several ranks "no class anywhere"
         // is "no aligned unit anywhere" (every aligned unit belongs to a class)
         if (q->comm ? aligned == 0 : C == 0) {
+            if (effective_lengths)
+                HIP_TRY(hipMemcpyAsync(effective_lengths, q->eff_len.p, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
             HIP_TRY(hipStreamSynchronize(q->stream));
             if (tpm) memset(tpm, 0, (size_t)n_tx * 8);
             if (iters) *iters = 0;
@@ -2025,6 +2039,8 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         launch_divide(x, n_tx, total + 1, false, 0.0, q->stream);
         HIP_TRY(hipGetLastError());
         if (tpm) HIP_TRY(hipMemcpyAsync(tpm, x, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
+        if (effective_lengths)
+            HIP_TRY(hipMemcpyAsync(effective_lengths, q->eff_len.p, n_tx * 8, hipMemcpyDeviceToHost, q->stream));
         HIP_TRY(hipStreamSynchronize(q->stream));
         lap("tpm");
         if (iters) *iters = it;
