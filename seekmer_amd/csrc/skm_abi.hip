@@ -226,7 +226,9 @@ struct skm_quant {
     struct Batch {
         DBuf<double> cls_count, inner, row_sum, x0, x1, part_max;
         DBuf<unsigned int> part_flags;
-        DBuf<unsigned long long> ctl;
+        DBuf<unsigned long long> ctl, mgr;
+        DBuf<double> counts_all;              // [group][C] pre-drawn class counts of a group of replicates
+        DBuf<int64_t> iters;                  // [group] their step counts
     } batch;
     double n_total = 0;
     bool n_total_reduced = false;             // n_total already is the sum over all ranks
@@ -2066,6 +2068,7 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->cum.release(); q->tile_total.release(); q->x_start.release(); q->boot_out.release();
     q->batch.cls_count.release(); q->batch.inner.release(); q->batch.row_sum.release(); q->batch.x0.release();
     q->batch.x1.release(); q->batch.part_max.release(); q->batch.part_flags.release(); q->batch.ctl.release();
+    q->batch.mgr.release(); q->batch.counts_all.release(); q->batch.iters.release();
     for (auto &e : q->ev) pool_event_release(e, true);
     for (auto &e : q->chunk_ev) pool_event_release(e, false);
     pool_pinned_release(q->pinned);
@@ -2217,7 +2220,18 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
         }
         return rc;
     }
-    const int64_t slots = std::max<int64_t>(1, group);
+    // EM_BATCH replicates sit side by side in the batched EM (skm_em_batch.hip) and THE DEVICE keeps the
+    // working set full: the class counts of a whole group of replicates are drawn first (HBM has the
+    // room: 8 MB per replicate at a million classes), and after every step two small launches take
+    // the results of the replicates that have latched their stopping rule and put the next ones in
+    // their places (launch_em_batch_manage) -- no host look between steps; the host queues steps
+    // and reads now and then how many replicates have finished.  (Through round 3's first half the
+    // host looked every four steps and refilled: ~100 looks and a fifth of the phase's wall time in
+    // gaps.)  Step counts have a long tail (most replicates of the 20 M-pair table stop near 30
+    // steps, one in six needs 60-90); every replicate still runs the single-problem EM's steps bit
+    // for bit, whoever its neighbours are and whenever it starts.
+    const int64_t by_counts = std::max<int64_t>(1, (int64_t)((1LL << 31) / (8 * std::max<int64_t>(C, 1))));
+    const int64_t slots = std::max<int64_t>(1, std::min(group, by_counts));
     SKM_TRY(q->boot_out.ensure((size_t)(slots * T)));
     skm_quant::Batch &w = q->batch;
     SKM_TRY(w.cls_count.ensure((size_t)C * EM_BATCH)); SKM_TRY(w.inner.ensure((size_t)C * EM_BATCH));
@@ -2226,6 +2240,9 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     SKM_TRY(w.part_max.ensure((size_t)EM_FINAL_BLOCKS * EM_BATCH));
     SKM_TRY(w.part_flags.ensure((size_t)EM_FINAL_BLOCKS * EM_BATCH));
     SKM_TRY(w.ctl.ensure(32));
+    SKM_TRY(w.mgr.ensure(64));
+    SKM_TRY(w.counts_all.ensure((size_t)slots * C));
+    SKM_TRY(w.iters.ensure((size_t)slots));
     EmBatchProblem p{};
     p.n_tx = T; p.n_classes = C; p.n_rows = q->n_rows;
     p.cls_offset = q->cls_offset.p; p.ids = q->ids.p; p.row_start = q->row_start.p; p.row_tx = q->row_tx.p;
@@ -2234,79 +2251,69 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     p.x[0] = w.x0.p; p.x[1] = w.x1.p;
     p.n_total = (double)n_draws; p.rel_tol = rel_tol; p.x_floor = x_floor;
     p.ctl = w.ctl.p; p.part_max = w.part_max.p; p.part_flags = w.part_flags.p;
-    int64_t chunk = 4;                                           // steps between two looks at the working set
+    p.managed = 1;
+    int64_t chunk = 16;                                          // steps queued between two looks at the progress
     if (const char *e = getenv("SKM_BOOTSTRAP_CHUNK")) chunk = std::max<int64_t>(1, atoll(e));   // (tests)
-    unsigned long long *const verdict = q->pinned + 64;          // 32 words of the pinned block
-    // the results of `slots` replicates at a time collect in boot_out and go home together
+    unsigned long long *const look = q->pinned + 64;             // 64 + 8 words of the pinned block
+    std::vector<int64_t> iters_host((size_t)slots);
     for (int64_t w0 = 0; w0 < n_boot; w0 += slots) {
-        const int64_t w1 = std::min(n_boot, w0 + slots);
-        int64_t place[EM_BATCH], since[EM_BATCH];                // the replicate in each place (-1: none), its first step
-        int64_t next = w0, k = 0;                                // next replicate to start; steps queued so far
-        unsigned int idle = 0;
-        auto start = [&](int r) -> int {                         // replicate `next` into place r, from step k on
-            if (!launch_multinomial(q->cum.p, C, n_draws, seed, number(next), q->tile_total.p,
-                                    w.cls_count.p + r, EM_BATCH, q->stream))
+        const int64_t n = std::min(n_boot, w0 + slots) - w0;
+        for (int64_t i = 0; i < n; ++i)
+            if (!launch_multinomial(q->cum.p, C, n_draws, seed, number(w0 + i), q->tile_total.p,
+                                    w.counts_all.p + (size_t)i * C, 1, q->stream))
                 return fail(SKM_ERR_STATE, "class table too large to resample (%lld classes)", (long long)C);
-            launch_em_batch_place(q->x_start.p, T, r, p.x[k & 1], p.part_max, p.part_flags, q->stream);
-            place[r] = next++;
-            since[r] = k;
-            return SKM_OK;
-        };
-        for (int r = 0; r < EM_BATCH; ++r) {
-            place[r] = -1;
-            if (next < w1) SKM_TRY(start(r)); else idle |= 1u << r;
-        }
-        launch_em_batch_ctl(w.ctl.p, idle, q->stream);
-        for (;;) {
-            for (int64_t i = 0; i < chunk; ++i) launch_em_batch_step(p, k + i, q->stream);
-            launch_em_batch_decide(p, k + chunk, q->stream);
-            q->launches += 3 * chunk + 1;
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(verdict, w.ctl.p, 32 * 8, hipMemcpyDeviceToHost, q->stream));
-            HIP_TRY(hipStreamSynchronize(q->stream));
-            // (all stopped before the chunk's end: the steps after that one did nothing)
-            k = verdict[0] ? (int64_t)verdict[1] : k + chunk;
-            bool any = false;
-            for (int r = 0; r < EM_BATCH; ++r) {
-                if (place[r] < 0) continue;
-                if (!verdict[8 + r]) { any = true; continue; }
-                if (verdict[24 + r])
-                    return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
-                const int64_t steps = (int64_t)verdict[16 + r] - since[r];
-                if (iters_out) iters_out[place[r]] = steps;
-                q->iters_total += (double)steps;
-                // a stopped replicate is carried from buffer to buffer: the one step k would read holds it
-                launch_em_batch_take(p.x[k & 1], T, r, q->boot_out.p + (place[r] - w0) * T, q->stream);
-                place[r] = -1;
-                if (next < w1) { SKM_TRY(start(r)); any = true; } else idle |= 1u << r;
+        launch_em_batch_manage_init(p, w.mgr.p, look, n, w.counts_all.p, q->x_start.p, q->boot_out.p, q->stream);
+        HIP_TRY(hipGetLastError());
+        for (int64_t k = 0;;) {
+            for (int64_t i = 0; i < chunk; ++i, ++k) {
+                launch_em_batch_step(p, k, q->stream);
+                launch_em_batch_manage(p, w.mgr.p, w.counts_all.p, q->x_start.p, q->boot_out.p, w.iters.p, k, q->stream);
             }
+            // before the host looks, the last pass is judged too (otherwise only the next step's first
+            // kernel would) and what it stops is taken: a place that is still occupied then is running
+            launch_em_batch_decide(p, k, q->stream);
+            launch_em_batch_manage(p, w.mgr.p, w.counts_all.p, q->x_start.p, q->boot_out.p, w.iters.p, k - 1, q->stream);
+            q->launches += 5 * chunk + 3;
             HIP_TRY(hipGetLastError());
-            if (!any) break;
+            HIP_TRY(hipMemcpyAsync(look, w.mgr.p, 24 * 8, hipMemcpyDeviceToHost, q->stream));
+            HIP_TRY(hipMemcpyAsync(look + 24, w.ctl.p, 8 * 8, hipMemcpyDeviceToHost, q->stream));
+            HIP_TRY(hipStreamSynchronize(q->stream));
+            if (look[3])
+                return fail(SKM_ERR_UNDEFINED, "no abundance above x_floor: numpy raises on max() of an empty selection");
+            if (look[24]) break;                                 // every replicate of the group has finished
+            if (k > (1LL << 24)) return fail(SKM_ERR_STATE, "the bootstrap EM does not stop");
             // The tail: nothing left to put in, a few replicates still running.  A step of the
             // working set costs the same however many places are live (~5 single-problem steps), so
             // the last three or fewer go on one by one in the single-problem EM, from where they are.
             int live = 0;
-            for (int r = 0; r < EM_BATCH; ++r) live += place[r] >= 0;
-            if (next >= w1 && live <= 3) {
+            for (int r = 0; r < EM_BATCH; ++r) live += look[8 + r] != 0;
+            if (look[0] >= look[1] && live <= 3) {
                 for (int r = 0; r < EM_BATCH; ++r) {
-                    if (place[r] < 0) continue;
+                    if (look[8 + r] == 0) continue;
+                    const int64_t rep = (int64_t)look[8 + r] - 1, since = (int64_t)look[16 + r];
                     launch_em_batch_take(p.x[k & 1], T, r, q->x0.p, q->stream);
                     launch_em_batch_take(w.cls_count.p, C, r, q->cls_count.p, q->stream);
                     HIP_TRY(hipGetLastError());
                     q->n_total = (double)n_draws;
                     int64_t more = 0;
                     SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, &more, 8));
-                    HIP_TRY(hipMemcpyAsync(q->boot_out.p + (place[r] - w0) * T, (more & 1) ? q->x1.p : q->x0.p,
-                                           (size_t)T * 8, hipMemcpyDeviceToDevice, q->stream));
-                    if (iters_out) iters_out[place[r]] = k - since[r] + more;
-                    q->iters_total += (double)(k - since[r]);        // (em_run has counted its own)
-                    place[r] = -1;
+                    HIP_TRY(hipMemcpyAsync(q->boot_out.p + rep * T, (more & 1) ? q->x1.p : q->x0.p, (size_t)T * 8,
+                                           hipMemcpyDeviceToDevice, q->stream));
+                    const int64_t steps = k - since + more;
+                    HIP_TRY(hipMemcpyAsync(w.iters.p + rep, &steps, 8, hipMemcpyHostToDevice, q->stream));
+                    HIP_TRY(hipStreamSynchronize(q->stream));      // (`steps` lives on this frame)
+                    q->iters_total -= (double)more;                // (em_run has counted its own; the sum below counts all)
                 }
                 break;
             }
-            launch_em_batch_ctl(w.ctl.p, idle, q->stream);
         }
-        SKM_TRY(send_home(w0, w1 - w0));
+        HIP_TRY(hipMemcpyAsync(iters_host.data(), w.iters.p, (size_t)n * 8, hipMemcpyDeviceToHost, q->stream));
+        HIP_TRY(hipStreamSynchronize(q->stream));
+        for (int64_t i = 0; i < n; ++i) {
+            if (iters_out) iters_out[w0 + i] = iters_host[(size_t)i];
+            q->iters_total += (double)iters_host[(size_t)i];
+        }
+        SKM_TRY(send_home(w0, n));
     }
     return rc;
 }

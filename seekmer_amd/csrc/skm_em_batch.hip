@@ -69,7 +69,9 @@ __device__ unsigned int evaluate_batch(const EmBatchProblem &p, int n_parts, int
     }
     __syncthreads();
     const unsigned int mask = s_mask;
-    if (publish && threadIdx.x == 0 && mask == (1u << R) - 1u && !p.ctl[BCTL_ALL_DONE]) {
+    // (who says "all done": the judge when the host fills the places -- nothing new can come before it
+    // looks --, the assign kernel when the device does: a place that stops is refilled in the same step)
+    if (publish && !p.managed && threadIdx.x == 0 && mask == (1u << R) - 1u && !p.ctl[BCTL_ALL_DONE]) {
         p.ctl[BCTL_LAST_STEP] = (unsigned long long)steps_done;
         p.ctl[BCTL_ALL_DONE] = 1;
     }
@@ -86,7 +88,7 @@ em_inner_batch_kernel(EmBatchProblem p, int parity, int eval_parts, int64_t step
     // block 0 judges the step before this one and latches what has stopped; the other blocks do not
     // wait (see em_inner_kernel: a pass of `inner` nobody reads, once per batch)
     if (eval_parts > 0 && blockIdx.x == 0
-            && evaluate_batch(p, eval_parts, steps_done, true) == (1u << R) - 1u) return;
+            && evaluate_batch(p, eval_parts, steps_done, true) == (1u << R) - 1u && !p.managed) return;
     // R lanes per class, lane r = replicate r: the R lanes of a class read one 64-byte sector of x per
     // id together and four ids are in flight per lane (one lane per class with the replicates in
     // registers had ONE dependent 64-byte gather in flight per lane: 86 us per step against 50 for the
@@ -220,26 +222,85 @@ em_decide_batch_kernel(EmBatchProblem p, int n_parts, int64_t steps_done)
     evaluate_batch(p, n_parts, steps_done, true);
 }
 
-// a new replicate in place r: x[t][r] = start[t], and the partials of "the step before" say
-// "selected, changing" for it, so that whoever judges next leaves it running
-__global__ void __launch_bounds__(256)
-em_batch_place_kernel(const double *__restrict__ start, int64_t n_tx, int r, double *__restrict__ x,
-                      double *__restrict__ part_max, unsigned int *__restrict__ part_flags)
-{
-    const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    for (int64_t i = i0; i < n_tx; i += (int64_t)gridDim.x * blockDim.x) x[i * R + r] = start[i];
-    if (i0 < EM_FINAL_BLOCKS) {
-        part_max[i0 * R + r] = 1e300;
-        part_flags[i0 * R + r] = 1u;
-    }
-}
-
 // out[t] = x[t][r]
 __global__ void __launch_bounds__(256)
 em_batch_take_kernel(const double *__restrict__ x, int64_t n_tx, int r, double *__restrict__ out)
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_tx;
          i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i * R + r];
+}
+
+// ---- the working set kept full by the device (`-b N`): after every step one small kernel decides,
+// place by place, what a latched stop means -- the replicate's step count is recorded, its result is
+// to be taken, the next replicate of the group (if any) is to be put in its place -- and a grid-wide
+// kernel carries the plan out: result out, pre-drawn class counts and the common start vector in,
+// the place's partials of "the step before" set to "still changing".  The host only queues steps
+// and looks now and then whether everything has finished.  mgr words: [0] next replicate to start,
+// [1] replicates in the group, [2] finished, [3] a replicate had no abundance above x_floor,
+// [8 + r] replicate in place r + 1 (0: idle), [16 + r] the step it started at, [24 + r] / [32 + r]
+// the plan of this step: replicate to take / to put, + 1.
+enum { MGR_NEXT = 0, MGR_COUNT = 1, MGR_FINISHED = 2, MGR_UNDEFINED = 3, MGR_REP = 8, MGR_SINCE = 16, MGR_TAKE = 24,
+       MGR_PUT = 32 };
+
+__global__ void em_batch_assign_kernel(EmBatchProblem p, unsigned long long *mgr, int64_t *iters_out, int64_t step)
+{
+    if (threadIdx.x != 0 || p.ctl[BCTL_ALL_DONE]) return;
+    bool any = false;
+    for (int r = 0; r < R; ++r) {
+        unsigned long long take = 0, put = 0;
+        if (mgr[MGR_REP + r] != 0 && p.ctl[BCTL_DONE + r]) {
+            const unsigned long long rep = mgr[MGR_REP + r] - 1;
+            if (iters_out) iters_out[rep] = (int64_t)(p.ctl[BCTL_ITERS + r] - mgr[MGR_SINCE + r]);
+            if (p.ctl[BCTL_UNDEFINED + r]) mgr[MGR_UNDEFINED] = 1;
+            take = rep + 1;
+            mgr[MGR_FINISHED] += 1;
+            if (mgr[MGR_NEXT] < mgr[MGR_COUNT]) {
+                put = ++mgr[MGR_NEXT];                              // (replicate mgr[MGR_NEXT] - 1, + 1)
+                mgr[MGR_REP + r] = put;
+                mgr[MGR_SINCE + r] = (unsigned long long)(step + 1);
+                p.ctl[BCTL_DONE + r] = 0;
+                p.ctl[BCTL_UNDEFINED + r] = 0;
+                p.ctl[BCTL_ITERS + r] = 0;
+            } else {
+                mgr[MGR_REP + r] = 0;                               // idle from now on (it stays "stopped")
+            }
+        }
+        mgr[MGR_TAKE + r] = take;
+        mgr[MGR_PUT + r] = put;
+        any |= mgr[MGR_REP + r] != 0;
+    }
+    if (!any) {
+        p.ctl[BCTL_LAST_STEP] = (unsigned long long)(step + 1);
+        p.ctl[BCTL_ALL_DONE] = 1;
+    }
+}
+
+// the plan carried out; `into` = the abundance buffer the NEXT step reads (a stopped replicate's
+// result is carried there by the finalize pass of this step)
+__global__ void __launch_bounds__(256)
+em_batch_refill_kernel(EmBatchProblem p, const unsigned long long *__restrict__ mgr, const double *__restrict__ counts_all,
+                       const double *__restrict__ x_start, double *__restrict__ out_all, double *__restrict__ into)
+{
+    __shared__ unsigned long long plan[2 * R];
+    if (threadIdx.x < 2 * R) plan[threadIdx.x] = mgr[MGR_TAKE + threadIdx.x];     // (TAKE and PUT are adjacent)
+    __syncthreads();
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 2 * R; ++i) any |= plan[i] != 0;
+    if (!any) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double *cls_count = const_cast<double *>(p.cls_count);
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long take = plan[r], put = plan[R + r];
+        if (take)
+            for (int64_t t = first; t < p.n_tx; t += stride) out_all[(int64_t)(take - 1) * p.n_tx + t] = into[t * R + r];
+        if (put) {
+            for (int64_t t = first; t < p.n_tx; t += stride) into[t * R + r] = x_start[t];
+            const double *counts = counts_all + (int64_t)(put - 1) * p.n_classes;
+            for (int64_t c = first; c < p.n_classes; c += stride) cls_count[c * R + r] = counts[c];
+            if (first < EM_FINAL_BLOCKS) { p.part_max[first * R + r] = 1e300; p.part_flags[first * R + r] = 1u; }
+        }
+    }
 }
 
 // fresh control block; the places in `idle` hold no replicate and count as stopped
@@ -277,16 +338,36 @@ void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t str
                        parity);
 }
 
+// the device-managed working set: set up for `n_reps` replicates (places 0 .. min(n_reps, 8) - 1 filled
+// from counts_all[0 ..]), then after every step em_batch_manage
+void launch_em_batch_manage_init(const EmBatchProblem &p, unsigned long long *mgr, unsigned long long *host, int64_t n_reps,
+                                 const double *counts_all, const double *x_start, double *out_all, hipStream_t stream)
+{
+    for (int i = 0; i < 64; ++i) host[i] = 0;          // (64 words of page-locked memory of the caller's)
+    const int filled = (int)std::min<int64_t>(n_reps, EM_BATCH);
+    host[MGR_NEXT] = (unsigned long long)filled;
+    host[MGR_COUNT] = (unsigned long long)n_reps;
+    unsigned int idle = 0;
+    for (int r = 0; r < EM_BATCH; ++r) {
+        if (r < filled) { host[MGR_REP + r] = (unsigned long long)r + 1; host[MGR_PUT + r] = (unsigned long long)r + 1; }
+        else idle |= 1u << r;
+    }
+    (void)hipMemcpyAsync(mgr, host, 64 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
+    hipLaunchKernelGGL(em_batch_ctl_kernel, dim3(1), dim3(64), 0, stream, p.ctl, idle);
+    hipLaunchKernelGGL(em_batch_refill_kernel, dim3(1024), dim3(256), 0, stream, p, mgr, counts_all, x_start, out_all, p.x[0]);
+}
+
+void launch_em_batch_manage(const EmBatchProblem &p, unsigned long long *mgr, const double *counts_all, const double *x_start,
+                            double *out_all, int64_t *iters_out, int64_t step, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_batch_assign_kernel, dim3(1), dim3(64), 0, stream, p, mgr, iters_out, step);
+    hipLaunchKernelGGL(em_batch_refill_kernel, dim3(1024), dim3(256), 0, stream, p, mgr, counts_all, x_start, out_all,
+                       p.x[(step + 1) & 1]);
+}
+
 void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream)
 {
     hipLaunchKernelGGL(em_decide_batch_kernel, dim3(1), dim3(256), 0, stream, p, em_batch_final_blocks(p), steps_done);
-}
-
-void launch_em_batch_place(const double *start, int64_t n_tx, int r, double *x, double *part_max,
-                           unsigned int *part_flags, hipStream_t stream)
-{
-    hipLaunchKernelGGL(em_batch_place_kernel, dim3(grid_of(std::max<int64_t>(n_tx, EM_FINAL_BLOCKS), 256)), dim3(256), 0,
-                       stream, start, n_tx, r, x, part_max, part_flags);
 }
 
 void launch_em_batch_take(const double *x, int64_t n_tx, int r, double *out, hipStream_t stream)

@@ -184,14 +184,21 @@ struct EmBatchProblem {
     unsigned long long *ctl;
     double *part_max;             // [EM_FINAL_BLOCKS][EM_BATCH]
     unsigned int *part_flags;     // [EM_FINAL_BLOCKS][EM_BATCH]
+    int managed;                  // the device refills the places (launch_em_batch_manage): see skm_em_batch.hip
 };
+// The working set kept full by the device: `mgr` is 64 words of HBM; counts_all[i][C] the pre-drawn
+// class counts of replicate i of the group, out_all[i][T] its result, iters_out[i] its step count
+// (device memory).  _init fills the first places; _manage after EVERY step takes what has stopped and
+// puts the next replicates in.  ctl[0] is set once every replicate of the group has finished; mgr[2]
+// counts the finished ones, mgr[3] != 0: a replicate had no abundance above x_floor.
+void launch_em_batch_manage_init(const EmBatchProblem &p, unsigned long long *mgr, unsigned long long *host_pinned64,
+                                 int64_t n_reps, const double *counts_all, const double *x_start, double *out_all,
+                                 hipStream_t stream);
+void launch_em_batch_manage(const EmBatchProblem &p, unsigned long long *mgr, const double *counts_all, const double *x_start,
+                            double *out_all, int64_t *iters_out, int64_t step, hipStream_t stream);
 // one step (inner, rows, finalize); step > 0 first judges the step before it
 void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream);
 void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream);
-// a new replicate in place r of the working set: x[t][r] = start[t] in the buffer the next step
-// reads, the previous step's partials for r set to "still changing"
-void launch_em_batch_place(const double *start, int64_t n_tx, int r, double *x, double *part_max,
-                           unsigned int *part_flags, hipStream_t stream);
 // out[t] = x[t][r]
 void launch_em_batch_take(const double *x, int64_t n_tx, int r, double *out, hipStream_t stream);
 // fresh control block; bit r of `idle`: place r holds no replicate and counts as stopped
