@@ -21,7 +21,7 @@ rows = {}
 for path in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(path)):
         n = r['Kernel_Name']
-        for key in ('class_insert', 'class_verify', 'class_commit', 'map_units'):
+        for key in ('class_insert', 'class_verify', 'map_units'):
             if key in n:
                 rows.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6)
 # three batches on a fresh table (one or two launches each: a large batch on an empty table goes in two
