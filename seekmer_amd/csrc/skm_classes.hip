@@ -106,7 +106,10 @@ __device__ __forceinline__ uint64_t probe_claim_from(const ClassTable &t, unsign
 // batch) is verified on the spot: the slot's tuple word came with the probe (same 32-byte
 // sector), so class_verify's second random pass over the table is only left with the records that
 // met a class created in this very launch (unit_slot >= 0; the others leave -1).
-constexpr int INSERT_WIDTH = 4;
+#ifndef SKM_INSERT_WIDTH
+#define SKM_INSERT_WIDTH 4
+#endif
+constexpr int INSERT_WIDTH = SKM_INSERT_WIDTH;
 // Timing experiments only (scripts/build_variant.sh; the results of these builds are wrong):
 // 1 = no count / first-seen atomics, 2 = no probe (every record "found" in its home slot, no CAS),
 // 3 = neither: what is left is the streaming part of the kernel.

@@ -874,8 +874,9 @@ def test_baseline_config2_properties(oracle, native_libs, t190k):
     """BASELINE.json configs[1] at its full size -- the ~190k-transcript stand-in index
     (2 GiB k-mer table) and 10 M 2x100 pairs, where the oracle would need a minute per run --
     through properties that do not need it: totals, first-seen order, the same counter from two
-    uneven batches and from a second run (the scheduler is asynchronous, the integers must not
-    care), and the device quantification against the numpy one bit for bit."""
+    uneven batches, from a second run (the scheduler is asynchronous, the integers must not care) and
+    from the same reads packed on the host and pushed in pieces, and the device quantification
+    against the numpy one bit for bit."""
     from seekmer_amd import synth, mapper, common, infer
     ids, pool, tx_offsets, index = t190k
     n_units = 10_000_000
@@ -902,6 +903,21 @@ def test_baseline_config2_properties(oracle, native_libs, t190k):
     np.testing.assert_array_equal(counts2, counts)
     np.testing.assert_array_equal(first2, first_seen)
     np.testing.assert_array_equal(fld2, fld)
+
+    # the same reads packed on the host (2-bit code words, a piece per 1.5 M reads and stream, mate 2
+    # pieces cut elsewhere than mate 1's) and pushed: the table of the ASCII batch bit for bit
+    split.reset()
+    flat = bases[:2 * n_units * 100].reshape(n_units, 2, 100)
+    for s, size in ((0, 1_500_000), (1, 1_300_001)):
+        mate = np.ascontiguousarray(flat[:, s, :]).reshape(-1)
+        for lo in range(0, n_units, size):
+            hi = min(n_units, lo + size)
+            rm.push_packed(common.PackedReads.from_ascii(
+                np.concatenate([mate[100 * lo:100 * hi], np.zeros(1, np.uint8)]),
+                np.arange(hi - lo + 1, dtype=np.int64) * 100, stream=s, first_read=lo, paired=True))
+    for got, want in zip(split.export(), (offs, targets, counts, first_seen, fld)):
+        np.testing.assert_array_equal(got, want)
+    assert split.sizes() == whole.sizes()
 
     tpm_dev, iters_dev = infer.quantify_resident(whole, return_iters=True)
     tpm_again, iters_again = infer.quantify_resident(split, return_iters=True)
