@@ -4,7 +4,8 @@
 //   (b) as a compact u64 array (32 MiB), (c) as a compact u32 array (16 MiB);
 // then the same with the probe's 16-byte read of the slot in front of every add: (d) add into the slot
 // that was read, (e) add into the compact u64 array, (f) into the compact u32 array.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/atomic_layout scripts/micro/atomic_layout.hip && /tmp/atomic_layout
+//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/atomic_layout scripts/micro/atomic_layout.hip  (here: cross-compiles)
+//   gpurun -- gpurun_out/atomic_layout                                                              (on the box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
