@@ -4,8 +4,9 @@
 //   (b) as a compact u64 array (32 MiB), (c) as a compact u32 array (16 MiB);
 // then the same with the probe's 16-byte read of the slot in front of every add: (d) add into the slot
 // that was read, (e) add into the compact u64 array, (f) into the compact u32 array.
-//   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/atomic_layout scripts/micro/atomic_layout.hip  (here: cross-compiles)
-//   gpurun -- gpurun_out/atomic_layout                                                              (on the box)
+//   mkdir -p seekmer_amd/csrc/build_micro && hipcc --offload-arch=gfx950 -O3 \
+//       -o seekmer_amd/csrc/build_micro/atomic_layout scripts/micro/atomic_layout.hip      (cross-compiles without a GPU)
+//   seekmer_amd/csrc/build_micro/atomic_layout                                            (on a GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
