@@ -149,7 +149,7 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
     unsigned int unaligned = 0;
     bool all_same = true;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // (u walks the batch's RECORDS, skm_kernels.h: MapBatch; unit_slot / unit_claim are by record)
+    // (u walks the batch's RECORDS, skm_kernels.h: MapBatch; unit_slot is by record)
     // (every lane of a block runs the same number of iterations: the commit of an iteration is a
     // block-wide step)
     for (int64_t ub = blockIdx.x * (int64_t)blockDim.x; ub < b.n_units; ub += INSERT_WIDTH * stride) {
