@@ -33,12 +33,15 @@ struct PackedOut {
     int64_t uniform_len = -2;      // -2 no read yet, >= 0 every read so far this long, -1 ragged
     bool want_names = false;
 
-    void use(alloc_fn al, free_fn fr)      // the arrays that cross PCIe live in the caller's kind of memory
+    // The code words -- nearly all of what crosses PCIe -- live in the caller's kind of memory
+    // (page-locked: the copy is DMA straight out of the array).  Lengths (not sent at all when the
+    // reads of a piece are equally long) and exception entries (a few per thousand reads) stay in
+    // plain memory: page-locking costs about a millisecond per allocation whatever its size.
+    void use(alloc_fn al, free_fn fr)
     {
         if (codes.al == al && codes.fr == fr) return;
-        codes.release(); lengths.release(); exc_reads.release(); exc_masks.release();
-        codes.al = al; codes.fr = fr; lengths.al = al; lengths.fr = fr;
-        exc_reads.al = al; exc_reads.fr = fr; exc_masks.al = al; exc_masks.fr = fr;
+        codes.release();
+        codes.al = al; codes.fr = fr;
     }
     void start(int code_words, bool with_names)
     {
@@ -349,6 +352,25 @@ inline size_t walk_impl(const char *text, size_t n, size_t start, size_t stop, P
 {
     const char *const end = text + n;
     size_t at = start;
+    if (out.codes.cap == 0 && start < n) {
+        // a piece without arrays yet: size them for the whole range from the first record's extent
+        // BEFORE anything is allocated (growing a page-locked array means locking a new one)
+        const char *q = text + start;
+        size_t bases_len = 0;
+        for (int line = 0; line < 4 && q < end; ++line) {
+            const char *line_end = find_newline(q, end);
+            if (line == 1) bases_len = (size_t)(line_end - q);
+            q = line_end < end ? line_end + 1 : end;
+        }
+        const size_t record = (size_t)(q - (text + start)), span = (stop < n ? stop : n) - start;
+        if (out.n_reads == 0 && (int)((bases_len + 31) / 32) > out.cw && bases_len < (1u << 20))
+            out.cw = (int)((bases_len + 31) / 32);             // (nothing stored yet: no re-striding)
+        if (record >= 8) {
+            const size_t expect = span / record + span / record / 16 + 64;
+            out.codes.reserve(expect * (size_t)out.cw);
+            out.lengths.reserve(expect);
+        }
+    }
     while (at < stop && at < n) {
         // line i & 3 == 0: the name
         const char *name = text + at;
