@@ -149,64 +149,50 @@ __global__ void __launch_bounds__(256)
 em_finalize_batch_kernel(EmBatchProblem p, int parity)
 {
     if (p.ctl[BCTL_ALL_DONE]) return;
+    // R lanes per transcript, lane r = replicate r (as in em_inner_batch): a lane follows ONE chain of
+    // dependent loads instead of eight, and there are eight times the lanes to hide it.  The
+    // arithmetic per (transcript, replicate) is unchanged; maxima and flags do not care about order.
     __shared__ double s_max[4][R];
     __shared__ unsigned int s_flags[4][R];
     const double *__restrict__ x_old = p.x[parity];
     double *__restrict__ x_new = p.x[parity ^ 1];
-    unsigned int stopped = 0;                 // replicates that are frozen
-#pragma unroll
-    for (int r = 0; r < R; ++r) stopped |= p.ctl[BCTL_DONE + r] ? 1u << r : 0u;
-    double local_max[R];
-    unsigned int flags[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { local_max[r] = 0.0; flags[r] = 0; }
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < p.n_tx;
-         t += (int64_t)gridDim.x * blockDim.x) {
-        double a[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) a[r] = 0.0;
-        for (int64_t row = p.tx_row[t]; row < p.tx_row[t + 1]; ++row) {
-            const double *__restrict__ part = p.row_sum + row * R;
-#pragma unroll
-            for (int r = 0; r < R; ++r) a[r] += part[r];
-        }
-        const double l = p.eff_len[t];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double before = x_old[t * R + r];
-            double v = a[r] / l / p.n_total;                     // infer.py:158
-            if (v != v) v = 0.0;                                 // infer.py:159
-            if ((stopped >> r) & 1u) {
-                x_new[t * R + r] = before;                       // a stopped replicate keeps its result
-            } else {
-                x_new[t * R + r] = v;
-                if (v > p.x_floor) {                             // infer.py:160
-                    const double change = fabs(v - before) / v;
-                    if (change != change) flags[r] |= 2u;
-                    else if (change > local_max[r]) local_max[r] = change;
-                    flags[r] |= 1u;
-                }
+    const int r = threadIdx.x & (R - 1);
+    const bool stopped = p.ctl[BCTL_DONE + r] != 0;           // this lane's replicate is frozen
+    double local_max = 0.0;
+    unsigned int flags = 0;
+    for (int64_t t = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / R; t < p.n_tx;
+         t += ((int64_t)gridDim.x * blockDim.x) / R) {
+        double a = 0.0;
+        for (int64_t row = p.tx_row[t]; row < p.tx_row[t + 1]; ++row) a += p.row_sum[row * R + r];
+        const double before = x_old[t * R + r];
+        double v = a / p.eff_len[t] / p.n_total;                 // infer.py:158
+        if (v != v) v = 0.0;                                     // infer.py:159
+        if (stopped) {
+            x_new[t * R + r] = before;                           // a stopped replicate keeps its result
+        } else {
+            x_new[t * R + r] = v;
+            if (v > p.x_floor) {                                 // infer.py:160
+                const double change = fabs(v - before) / v;
+                if (change != change) flags |= 2u;
+                else if (change > local_max) local_max = change;
+                flags |= 1u;
             }
         }
     }
     const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        for (int d = 32; d > 0; d >>= 1) {
-            const double o = __shfl_xor(local_max[r], d, 64);
-            local_max[r] = o > local_max[r] ? o : local_max[r];
-            flags[r] |= __shfl_xor(flags[r], d, 64);
-        }
-        if ((threadIdx.x & 63) == 0) { s_max[wave][r] = local_max[r]; s_flags[wave][r] = flags[r]; }
+    for (int d = 32; d >= R; d >>= 1) {                          // over the lanes of the wave that hold replicate r
+        const double o = __shfl_xor(local_max, d, 64);
+        local_max = o > local_max ? o : local_max;
+        flags |= __shfl_xor(flags, d, 64);
     }
+    if ((threadIdx.x & 63) < R) { s_max[wave][r] = local_max; s_flags[wave][r] = flags; }
     __syncthreads();
     if (threadIdx.x < R) {
-        const int r = threadIdx.x;
         double m = s_max[0][r];
         unsigned int f = s_flags[0][r];
         for (int w = 1; w < 4; ++w) { m = s_max[w][r] > m ? s_max[w][r] : m; f |= s_flags[w][r]; }
         // a frozen replicate reports "selected, no change": it stays stopped whatever is judged
-        if ((stopped >> r) & 1u) { m = 0.0; f = 1u; }
+        if (stopped) { m = 0.0; f = 1u; }
         p.part_max[blockIdx.x * R + r] = m;
         p.part_flags[blockIdx.x * R + r] = f;
     }
@@ -322,7 +308,7 @@ inline unsigned grid_of(int64_t items, int per_block, int64_t cap = 256 * 8)
 
 int em_batch_final_blocks(const EmBatchProblem &p)
 {
-    int64_t blocks = (p.n_tx + 255) / 256;
+    int64_t blocks = (p.n_tx * EM_BATCH + 255) / 256;        // (a lane per transcript and replicate)
     if (blocks < 1) blocks = 1;
     if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
     return (int)blocks;
