@@ -13,7 +13,7 @@
  *   libseekmer_hip.so   -- everything that touches the GPU (skm_index_*,
  *                          skm_mapper_*, skm_quant_*, skm_comm_*, skm_device_*)
  *   libseekmer_host.so  -- host-side native code with no GPU dependency
- *                          (skm_build_*, skm_fastq_*, skm_synth_*)
+ *                          (skm_build_*, skm_fastq_*, skm_fastq_packed_*, skm_pack_*, skm_synth_*)
  */
 #ifndef SEEKMER_HIP_H
 #define SEEKMER_HIP_H
