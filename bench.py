@@ -38,14 +38,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_SUMMARY = os.path.join('profiles', 'r03_pmc_map.json')     # rocprofv3 --pmc passes of the map kernel
+PMC_SUMMARY = os.path.join('profiles', 'r04_pmc_map.json')     # rocprofv3 --pmc passes of the map kernel
+MAP_KERNEL_SOURCES = ('skm_map.hip', 'skm_device.h', 'skm_kernels.h')
+
+
+def map_source_hash():
+    """Digest of the map kernel's sources: scripts/pmc_finish.py stores it with the PMC summary, and
+    `roofline.traffic` is only quoted from a summary whose digest is the tree's (a kernel change
+    after the counter passes makes the quote null, not stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in MAP_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, 'seekmer_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def table_digest(map_result):
+    """sizes() and a digest of export() (class offsets, ids, counts, first-seen units, histogram)."""
+    import hashlib
+    h = hashlib.sha256()
+    for a in map_result.export():
+        h.update(np.ascontiguousarray(a).tobytes())
+    return tuple(int(v) for v in map_result.sizes()), h.hexdigest()[:16]
 
 
 def log(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units, paired, bootstraps=0):
+def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units, paired, bootstraps=0, gpu_table=None,
+                 parity=None):
     """The CPU oracle ("port" of the reference algorithm) on a bounded sample of the same
     workload: map + class counting + effective lengths + EM (+ `bootstraps` resamples, each a
     numpy multinomial draw and an EM from the main estimate, as seekmer/infer.py:108-111).
@@ -85,6 +108,26 @@ def cpu_baseline(index, pool, tx_offsets, seed, read_len, sample_units, paired, 
     t0 = time.perf_counter()
     tpm, iters, boot_s = quantify([result], fld)
     t_quant = time.perf_counter() - t0
+    if gpu_table is not None:
+        # the oracle as the checker (untimed): the HIP path's class table, histogram and TPM of the SAME
+        # sample against the ones just computed -- a mismatch fails the run
+        classes = O.Classes()
+        classes.update(result)
+        want = classes.export() + (fld,)
+        got, got_unaligned, got_tpm, got_iters = gpu_table(bases, offsets, sample_units)
+        same = (all(np.array_equal(g, w) for g, w in zip((got[0], got[1], got[2], got[4]), want))
+                and got_unaligned == classes.unaligned and got_iters == iters)
+        mask = tpm > 0
+        rel = float((np.abs(got_tpm[mask] - tpm[mask]) / tpm[mask]).max()) if mask.any() else 0.0
+        same = same and np.array_equal(got_tpm > 0, mask) and rel < 1e-4
+        parity['cpu_sample_vs_hip'] = {
+            'units': sample_units, 'classes': int(want[2].size), 'unaligned': int(classes.unaligned),
+            'tables_identical': bool(same), 'em_iterations': int(iters), 'tpm_max_rel_diff': rel,
+            'what': 'class offsets, ids, counts (first-seen order), fragment-length histogram and unaligned count of '
+                    'the oracle == the HIP path\'s on the cpu_baseline sample, EM step count equal, TPM within 1e-4'}
+        if not same:
+            raise SystemExit('parity check failed: the HIP path and the oracle disagree on the cpu_baseline sample: %s'
+                             % parity['cpu_sample_vs_hip'])
     del result
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -277,6 +320,31 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
                    'passes with the files\' mappings and the page-locked pieces kept between passes, `first_pass` '
                    'without either' % (2 * read_len + 19, threads, passes)}
 
+        # what ONE `seekmer infer` run sees: the same pass in a process of its own (nothing mapped,
+        # pooled or page-locked yet; the index upload is set-up, as it is for `first_pass`)
+        try:
+            index_path = args.index_cache if args.index_cache and os.path.exists(args.index_cache) \
+                else os.path.join(folder, 'index.npz')
+            if not os.path.exists(index_path):
+                index.save(index_path)
+            cmd = [sys.executable, os.path.abspath(__file__), '--cold-child', index_path, p1, p2,
+                   '--parse-threads', str(threads), '--e2e-chunk-mb', str(args.e2e_chunk_mb)]
+            colds = []
+            for _ in range(2):
+                import subprocess
+                done = subprocess.run(cmd, stdout=subprocess.PIPE, check=True, timeout=600)
+                colds.append(json.loads(done.stdout.decode().strip().splitlines()[-1]))
+            assert all(tuple(c['sizes']) == tuple(classes_host) for c in colds)
+            best_cold = min(colds, key=lambda c: c['total_s'])
+            out['fastq_inclusive']['cold_process'] = {
+                'value': n_units / best_cold['total_s'], 'unit': 'pairs/s',
+                'through_mapping': n_units / best_cold['map_s'],
+                'runs': [n_units / c['total_s'] for c in colds], 'setup_s': best_cold['setup_s'],
+                'how': 'the fastq_inclusive pass as the ONLY pass of a fresh process (python bench.py --cold-child: index '
+                       'load + upload are set-up, then FASTQ text -> TPM once); the faster of two such processes'}
+        except Exception as e:                      # (the leg is a report, not the metric)
+            out['fastq_inclusive']['cold_process'] = {'error': repr(e)}
+
         # last round's path beside it: newline index + ASCII slabs
         fastq_pieces = max(1, args.e2e_fastq_batches)
         batch_units = (n_units + fastq_pieces - 1) // fastq_pieces
@@ -300,7 +368,32 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
     return out
 
 
-SHAPES = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100)}
+def cold_child(args):
+    """`e2e.fastq_inclusive.cold_process`: what a one-shot `seekmer infer` run does after its index is
+    in HBM -- ONE pass from FASTQ text to TPM in a process that has mapped, pooled and page-locked
+    nothing yet."""
+    from seekmer_amd import _native, common, infer, mapper
+    index_path, r1, r2 = args.cold_child
+    t_start = time.perf_counter()
+    index = common.KMerIndex.load(index_path)
+    index.device_handle(0)
+    _native.check(_native.hip().skm_pinned_set_device(0))
+    result = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, result)
+    t0 = time.perf_counter()
+    feeder = common.PackedReadFeeder([r1, r2], True, threads=args.parse_threads,
+                                     chunk_bytes=args.e2e_chunk_mb << 20, pinned=True)
+    rm(feeder)
+    t_map = time.perf_counter() - t0
+    infer.quantify_resident(result)
+    total = time.perf_counter() - t0
+    print(json.dumps({'setup_s': t0 - t_start, 'map_s': t_map, 'total_s': total,
+                      'sizes': [int(v) for v in result.sizes()]}), flush=True)
+
+
+SHAPES = {1: (10_000_000, 100, True, 0), 3: (50_000_000, 150, False, 0), 4: (20_000_000, 100, True, 100),
+          # BASELINE.json north_star's target sentence: 50 M 2x100 pairs, ~200k-transcript index, one GPU
+          'north_star': (50_000_000, 100, True, 0)}
 
 
 def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=-1, with_cpu=True, with_e2e=False):
@@ -426,11 +519,24 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
     map_ns = (t_after['map_ns'] - t_before['map_ns']) / max(launches, 1)
     pack_ns = (t_after['pack_ns'] - t_before['pack_ns']) / max(launches, 1)
     class_ns = (t_after['class_ns'] - t_before['class_ns']) / max(launches, 1)
+    parity = {}
+    production = table_digest(result)      # the last timed step's table (bucket layout, production kernel)
     result.set_stats(True)                 # counting build, untimed: access counts per launch
     result.reset()
     result.map_resident(d_bases, d_offsets, n_units, paired, read_len)
     st = result.access_stats()
     result.set_stats(False)
+    counting = table_digest(result)        # the same units through the reference's table layout
+    parity['counting_vs_production'] = {
+        'units': n_units, 'sizes': list(production[0]), 'digest': production[1],
+        'identical': production == counting,
+        'what': 'sizes() and sha256 of export() of the counting build\'s launch (reference table layout, the '
+                'launch whose access counters are the roofline\'s algorithmic bytes) == the production launch\'s'}
+    if bootstraps and world > 1:
+        # (rank 0's table then holds the other ranks' merged in: not the launch's own any more)
+        parity['counting_vs_production']['identical'] = None
+    elif production != counting:
+        raise SystemExit('parity check failed: counting build %s != production build %s' % (counting, production))
     algorithmic = (st['read_bases'] + 16 * st['slots'] + 48 * st['contig_reads']
                    + 8 * (st['targets_copied'] + st['targets_merged']) + 8 * st['seq_fetches']
                    + 4 * st['tuple_ids'])
@@ -445,7 +551,9 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
     try:
         with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
             pmc = json.load(f)
-        if config == 1 and args.genes == 20000 and n_units == 10_000_000 and read_len == 100:
+        if pmc.get('source_hash') != map_source_hash():
+            traffic_source = 'null: %s was collected from other kernel sources than this tree\'s' % PMC_SUMMARY
+        elif config == 1 and args.genes == 20000 and n_units == 10_000_000 and read_len == 100:
             traffic = pmc['derived']['hbm_traffic_bytes']
             traffic_source = 'quoted from %s (rocprofv3 --pmc passes of this build on this workload), ' \
                              'not measured by this run' % PMC_SUMMARY
@@ -470,9 +578,9 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
             'dtype': 'u64+f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'configs[%d]: synthetic ~190k-tx index (stand-in for ENSEMBL GRCh38 cDNA), '
+                'workload': '%s: synthetic ~190k-tx index (stand-in for ENSEMBL GRCh38 cDNA), '
                             '%d %s synthetic %s per GPU, map+classes+EM to the reference stop rule%s'
-                            % (config, n_units, ('2x%dbp' if paired else '%dbp single-end') % read_len,
+                            % ('configs[%d]' % config if isinstance(config, int) else config, n_units, ('2x%dbp' if paired else '%dbp single-end') % read_len,
                                unit_name, ' + %d bootstraps (-b)' % bootstraps if bootstraps else ''),
                 'transcripts': n_tx, 'kmer_slots': int(index.kmers.size),
                 'units_per_gpu': n_units, 'read_len': read_len, 'paired': paired,
@@ -510,9 +618,18 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
                 line['config']['bootstrap_em_steps'] = state['boot_iters'] // steps
             line['config']['phase_ms']['bootstraps'] = 1e3 * state['boot_s'] / steps
         if with_cpu and world == 1:
+            def gpu_table(sample_bases, sample_offsets, sample_units):
+                from seekmer_amd import common
+                sample = mapper.MapResult(index, device=device)
+                mapper.ReadMapper(index, sample).map_batch(
+                    common.ReadBatch(sample_units, sample_bases, sample_offsets, paired))
+                sample_tpm, sample_iters = infer.quantify_resident(sample, return_iters=True)
+                return sample.export(), sample.sizes()[2], sample_tpm, sample_iters
+
             line['cpu_baseline'] = cpu_baseline(index, pool, tx_offsets, args.seed, read_len,
                                                 min(args.cpu_sample, n_units), paired,
-                                                bootstraps=min(bootstraps, 3))
+                                                bootstraps=min(bootstraps, 3), gpu_table=gpu_table, parity=parity)
+        line['parity_checked'] = parity
         if with_e2e and world == 1:
             del result
             _native.check(hip.skm_device_free(device, d_bases))
@@ -549,7 +666,11 @@ def main():
     ap.add_argument('--parse-threads', type=int, default=14)
     ap.add_argument('--e2e-chunk-mb', type=int, default=8, help='text range one parser thread takes at a time')
     ap.add_argument('--index-cache', default='', help='load/save the index here instead of building it')
+    ap.add_argument('--cold-child', nargs=3, metavar=('INDEX', 'R1', 'R2'), default=None,
+                    help='(internal) one FASTQ -> TPM pass in this fresh process; prints its times as JSON')
     args = ap.parse_args()
+    if args.cold_child:
+        return cold_child(args)
     args.read_len = args.read_len or SHAPES[args.config][1]
 
     rank = int(os.environ.get('RANK', '0'))
@@ -613,10 +734,10 @@ def main():
         # the other single-GPU configurations of BASELINE.json, a few steps each on the same index
         # (parity at these sizes: tests/test_gpu_parity.py::test_baseline_config{3,4}_properties)
         line['other_configs'] = {}
-        for other in (3, 4):
+        for other in (3, 4, 'north_star'):
             t0 = time.perf_counter()
-            sub = measure(args, ctx, other, args.other_steps, 1, with_cpu=False)
-            log('configs[%d]: %.1f M %s, %.1f ms per step (%.0fs with set-up)'
+            sub = measure(args, ctx, other, 2 if other == 'north_star' else args.other_steps, 1, with_cpu=False)
+            log('%s: %.1f M %s, %.1f ms per step (%.0fs with set-up)'
                 % (other, sub['value'] / 1e6, sub['unit'], sub['ms_per_step'], time.perf_counter() - t0))
             keep = {k: sub[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step')}
             keep['workload'] = sub['config']['workload']
@@ -626,7 +747,9 @@ def main():
                     keep[k] = sub['config'][k]
             keep['roofline'] = {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
                                                                 'algorithmic_bytes_per_launch', 'launch_ms')}
-            line['other_configs']['configs[%d]' % other] = keep
+            keep['parity_checked'] = sub['parity_checked']
+            line['other_configs']['configs[%d]' % other if isinstance(other, int)
+                                  else 'north_star: 50 M 2x100 pairs'] = keep
     if rank == 0:
         print(json.dumps(line), flush=True)
     if comm:

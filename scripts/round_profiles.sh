@@ -12,7 +12,7 @@ CACHE=/tmp/skm_idx.npz
 cd $ROOT
 # PMC passes first: bench.py quotes roofline.traffic from the committed summary of THIS build
 bash scripts/pmc_map.sh $TAG class_insert_kernel class_verify_kernel pack_reads_kernel > $OUT/pmc_$TAG.log 2>&1
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 python3 scripts/pmc_finish.py $OUT/pmc_$TAG.json profiles/${ROUND}_pmc_map.json
 cp profiles/${ROUND}_pmc_map.json $OUT/${TAG}_pmc_map.json
 python3 bench.py --index-cache $CACHE > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err

@@ -870,6 +870,65 @@ def _upload(native, array):
     return pointer
 
 
+@pytest.fixture(scope='module')
+def t190k_oracle_index(oracle, t190k):
+    ids, pool, tx_offsets, index = t190k
+    return oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                              lengths=np.diff(tx_offsets))
+
+
+@pytest.mark.parametrize('config,seed,read_len,paired', [(1, 1, 100, True), (3, 3, 150, False)])
+def test_t190k_slices_against_the_oracle(oracle, native_libs, t190k, t190k_oracle_index, config, seed,
+                                         read_len, paired):
+    """The benchmarked scale, unit by unit.  The first 300 k units of BASELINE.json configs[1]'s
+    read set (2x100 pairs) and of configs[3]'s (150-base single-end reads) against the index the
+    bench line is quoted on (2^27 slots, 4 GiB bucket copy, > 64-target mask extensions) through
+    the production kernels AND through the counting build, each compared with the oracle on the
+    same index arrays: per-unit span, anchor and signed target list, the class table in first-seen
+    order, the fragment-length histogram, the quantification (iteration count equal, TPM <= 1e-4:
+    north_star's tolerance), and every access counter of the counting build -- the numerator of
+    bench.py's roofline.achieved -- field by field (seekmer/_common.pyx:54-97, _mapper.pyx:111-343)."""
+    from seekmer_amd import synth, mapper, common, infer
+    ids, pool, tx_offsets, index = t190k
+    oindex = t190k_oracle_index
+    n_units = 300_000
+    bases, offsets = synth.reads(seed, pool, tx_offsets, 0, n_units, read_len, paired)
+    fld = np.zeros(2000, dtype=np.int64)
+    ostats = oracle.Stats()
+    expected = oracle.map_batch(oindex, bases, offsets, n_units, paired, fld, stats=ostats)
+    assert index.device_info()['bucketed'] == 1               # the production probe, not the fallback
+    result, units = _run_gpu(index, bases, offsets, n_units, paired)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+    classes = oracle.Classes()
+    classes.update(expected)
+    class_map, class_count = classes.summarize()
+    eff = oracle.effective_lengths(fld, oindex.lengths)
+    tpm_ref, iters_ref = oracle.quantify(eff, class_map, class_count)
+    tpm_dev, iters_dev, eff_dev = infer.quantify_resident(result, return_iters=True,
+                                                          return_effective_lengths=True)
+    np.testing.assert_array_equal(eff_dev, eff)
+    assert iters_dev == iters_ref, (iters_dev, iters_ref)
+    mask = tpm_ref > 0
+    np.testing.assert_array_equal(tpm_dev > 0, mask)
+    rel = np.abs(tpm_dev[mask] - tpm_ref[mask]) / tpm_ref[mask]
+    assert rel.max() < 1e-4, rel.max()
+
+    counting = mapper.MapResult(index, keep_spans=True)
+    counting.set_stats(True)
+    rm = mapper.ReadMapper(index, counting)
+    rm.map_batch(common.ReadBatch(n_units, bases, offsets, paired))
+    _compare_units(expected, rm.last_batch(n_units))
+    _compare_tables(oracle, expected, fld, counting)
+    counted = counting.access_stats()
+    for name, value in ostats.as_dict().items():
+        assert counted[name] == value, (name, counted[name], value)
+    assert (counted['read_bases'] + 16 * counted['slots'] + 48 * counted['contig_reads']
+            + 8 * (counted['targets_copied'] + counted['targets_merged']) + 8 * counted['seq_fetches']
+            + 4 * counted['tuple_ids']) == ostats.algorithmic_bytes()
+
+
 def test_baseline_config2_properties(oracle, native_libs, t190k):
     """BASELINE.json configs[1] at its full size -- the ~190k-transcript stand-in index
     (2 GiB k-mer table) and 10 M 2x100 pairs, where the oracle would need a minute per run --
