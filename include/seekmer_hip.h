@@ -97,7 +97,12 @@ int skm_index_info(const skm_index *index, int64_t info[8]);
  * under a cheap hash, one sector per lookup.  layout[0]=1 when that copy is in use, 0 when
  * the reference's own layout is probed (a table the reference's probe does not reach
  * everywhere, or one holding a k-mer twice); [1]=buckets [2]=k-mers placed [3]=placed outside
- * their home bucket [4]=k-mers met twice [5]=slots the reference's probe does not reach. */
+ * their home bucket [4]=k-mers met twice [5]=slots the reference's probe does not reach
+ * [6]=1 when every contig record carries its junction successors: the map_kmer results of the
+ * eight k-mers a hop of _filter_targets_to_left/right (seekmer/_mapper.pyx:246-248, 308-310) can
+ * ask for when it leaves the contig, computed once at upload, so that a hop reads its answer
+ * from the record instead of visiting the k-mer table (results identical by construction;
+ * off for a table probed in the reference's layout). */
 int skm_index_layout(const skm_index *index, int64_t layout[8]);
 
 /* ------------------------------------------------------------------ mapper
@@ -141,11 +146,15 @@ int skm_mapper_sync(skm_mapper *mapper);
  * of those bits set.  A piece carries its reads as code words only (32 bases per u64 word, first
  * base in the top two bits, zero beyond the read's end: 32 bytes for a 100-base read) plus an
  * exception entry -- the bit plane -- for each read that holds any other character. */
+#define SKM_PACKED_CUT (-1)
 typedef struct skm_packed_reads {
     int32_t stream;                  /* 0 = single-end reads / mate 1 files, 1 = mate 2 files */
-    int32_t code_words;              /* u64 words per read in `codes` */
+    int32_t code_words;              /* u64 words per read in `codes`; SKM_PACKED_CUT with n_reads == 0: a cut */
     int64_t first_read;              /* place of reads[0] in its stream = the unit it belongs to */
-    int64_t n_reads;                 /* 0 = end of the sample */
+    int64_t n_reads;                 /* 0 = end of the sample -- or, with code_words == SKM_PACKED_CUT, a cut:
+                                        the stream's reads from first_read on are dropped (the reader sends
+                                        one when the mate-2 file of a pair of files was the longer one, before
+                                        any read of the next pair of files) and more pieces follow */
     int64_t read_stride;             /* u64 words from one read's codes to the next (>= code_words) */
     int64_t uniform_len;             /* >= 0: every read is this long and `lengths` may be NULL */
     const uint64_t *codes;           /* read r = codes[r * read_stride .. + code_words) */
@@ -162,14 +171,15 @@ typedef struct skm_packed_reads {
  * stream; the mapper's worker maps, in the background and in launches as large as what has arrived,
  * every run of units that its streams cover (single-ended: stream 0 alone; paired: unit u = read u
  * of stream 0 + read u of stream 1).  A piece whose first_read lies below the end of what its stream
- * holds replaces the reads from there on.  skm_mapper_sync -- and every call that reads the table
+ * holds replaces the reads from there on (a cut -- see skm_packed_reads -- replaces them by
+ * nothing; either waits for a launch that is mapping from the replaced piece).  skm_mapper_sync -- and every call that reads the table
  * -- first maps every unit whose reads have all arrived; reads still without a mate are not part
  * of any result (zip(file1, file2): seekmer/common.py:180-197) and wait in HBM until their mates
  * come or the handle is reset, cleared or destroyed.  Class order does not depend on how the
  * pieces were cut or when they arrived: first-seen values are unit numbers. */
 int skm_mapper_push_packed(skm_mapper *mapper, const skm_packed_reads *piece, int paired);
 /* Drain a source of pieces (skm_fastq_packed_next with its reader as context) into the mapper
- * without leaving native code: next() until a piece with n_reads == 0, every piece pushed.
+ * without leaving native code: next() until a piece with n_reads == 0 that is not a cut, every piece pushed.
  * *n_pieces (optional) = pieces pushed. */
 typedef int (*skm_packed_source)(void *context, skm_packed_reads *piece);
 int skm_mapper_map_packed_source(skm_mapper *mapper, skm_packed_source next, void *context,

@@ -81,7 +81,7 @@ class KMerIndex:
         layout = (ctypes.c_int64 * 8)()
         _native.check(_native.hip().skm_index_layout(self.device_handle(device), layout))
         out.update(zip(('bucketed', 'buckets', 'bucket_kmers', 'bucket_overflowed', 'kmers_twice',
-                        'slots_unreached'), layout))
+                        'slots_unreached', 'successors'), layout))
         return out
 
     def release(self):
@@ -447,6 +447,9 @@ class NativeReadFeeder:
 
 
 # ------------------------------------------------------------- packed pieces
+PACKED_CUT = -1        # include/seekmer_hip.h: SKM_PACKED_CUT
+
+
 class PackedReads:
     """Reads as the mapper takes them: 2-bit code words (32 bases per uint64, first base in the top
     two bits; seekmer/_kmer.pxd:253-273), lengths, and -- only for reads that hold a character
@@ -509,8 +512,20 @@ class PackedReads:
         raw = ctypes.string_at(r.names, int(offsets[-1])) if offsets[-1] else b''
         return [raw[offsets[i]:offsets[i + 1]] for i in range(r.n_reads)]
 
+    is_cut = property(lambda self: self.raw.n_reads == 0 and self.raw.code_words == PACKED_CUT)
+
+    @classmethod
+    def cut(cls, stream, first_read, paired=True):
+        """The piece that drops what `stream` holds from `first_read` on (SKM_PACKED_CUT)."""
+        raw = _native.PackedReads()
+        raw.stream, raw.code_words, raw.first_read, raw.n_reads = int(stream), PACKED_CUT, int(first_read), 0
+        raw.uniform_len = -1
+        return cls(raw, paired=paired)
+
     def copy(self):
         """The same piece over arrays of its own."""
+        if self.is_cut:
+            return PackedReads.cut(self.stream, self.first_read, self.paired)
         return PackedReads.from_arrays(self.stream, self.first_read, numpy.array(self.codes), numpy.array(self.lengths),
                                        *[numpy.array(a) for a in self.exceptions], paired=self.paired)
 
@@ -628,7 +643,9 @@ class _PackedReader:
         raw = _native.PackedReads()
         _native.check_host(_native.host().skm_fastq_packed_next(self.handle, ctypes.byref(raw)),
                            'skm_fastq_packed_next')
-        return PackedReads(raw, keep=self, paired=self.paired) if raw.n_reads else None
+        if raw.n_reads == 0 and raw.code_words != PACKED_CUT:
+            return None
+        return PackedReads(raw, keep=self, paired=self.paired)       # (a piece or a cut)
 
     def stats(self):
         out = (ctypes.c_int64 * 8)()

@@ -197,6 +197,8 @@ struct skm_mapper {
     hipStream_t packed_stream = nullptr;
     int packed_paired = -1;                   // -1 until the first piece
     int packed_flush = 0;                     // callers waiting for everything mappable to be mapped
+    int packed_waiters = 0;                   // pushers held back by the byte limit: whatever run there is gets mapped
+    int64_t packed_max_pending = 8LL << 30;   // bytes of HBM that pieces may hold before a pusher waits
     bool packed_busy = false;
     int64_t packed_dropped = 0;               // reads that never got a mate
     // HBM held by pieces that wait to be mapped; a pusher that is ahead of the GPU by more than
@@ -374,7 +376,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     if (n_slots <= 0 || (n_slots & (n_slots - 1)) || n_slots > (1LL << 31))
         return fail(SKM_ERR_ARG, "k-mer table size %lld is not a power of two <= 2^31", (long long)n_slots);
     if (n_contigs <= 0 || n_bases < ALIGN_LENGTH || n_targets < 0 || n_bases >= (1LL << 31)
-            || n_targets + 16 * n_contigs >= (1LL << 30) || n_contigs >= (1LL << 26))
+            || n_targets + 32 * n_contigs >= (1LL << 30) || n_contigs >= (1LL << 25))
         return fail(SKM_ERR_ARG, "bad index sizes");
     int n_dev = 0;
     SKM_TRY(skm_device_count(&n_dev));
@@ -419,6 +421,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     const int n_workers = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(
                               std::max(1u, std::thread::hardware_concurrency()), 16u), n_slots >> 20));
     std::vector<int64_t> empty_part((size_t)n_workers, 0), bad_part((size_t)n_workers, -1);
+    std::vector<int> absent_part((size_t)n_workers, 0);      // a slot holds the offset DevContig::succ reserves
     {
         std::vector<std::thread> workers;
         for (int w = 0; w < n_workers; ++w)
@@ -427,6 +430,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                 int64_t empty = 0;
                 for (int64_t i = first; i < last; ++i) {
                     if (hk[i].kmer == KMER_INVALID) { ++empty; continue; }
+                    if (hk[i].pos.offset == SUCC_ABSENT) absent_part[(size_t)w] = 1;
                     const int32_t e = hk[i].pos.entry < 0 ? ~hk[i].pos.entry : hk[i].pos.entry;
                     if (hk[i].pos.offset >= 0
                             && (e < 0 || e >= n_contigs || hk[i].pos.offset + K > hc[e].length)) {
@@ -439,10 +443,12 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
         for (auto &t : workers) t.join();
     }
     int64_t empty = 0;
+    bool successors_ok = true;
     for (int w = 0; w < n_workers; ++w) {
         if (bad_part[(size_t)w] >= 0)
             return fail(SKM_ERR_ARG, "k-mer slot %lld points outside its contig", (long long)bad_part[(size_t)w]);
         empty += empty_part[(size_t)w];
+        successors_ok = successors_ok && !absent_part[(size_t)w];
     }
     if (empty == 0) return fail(SKM_ERR_ARG, "k-mer table has no empty slot");
 
@@ -467,7 +473,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
         std::vector<DevContig> rows((size_t)n_contigs);
         std::vector<int32_t> overflow;
         const Coord *ht = (const Coord *)targets;
-        const int64_t row_words = (int64_t)sizeof(DevContig) / 4;
+        const int64_t row_words = (int64_t)sizeof(DevContig) / 4;      // (int32 words per record)
         for (int64_t c = 0; c < n_contigs; ++c) {
             DevContig &d = rows[(size_t)c];
             memset(&d, 0, sizeof(d));
@@ -477,13 +483,12 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
             d.first_kmer = hc[c].first_kmer;
             d.last_kmer = hc[c].last_kmer;
             const int64_t first = hc[c].target_offset, count = hc[c].target_length;
-#if SKM_CONTIG_INLINE
+            for (int j = 0; j < 8; ++j) d.succ[j] = Coord{0, SUCC_ABSENT};
             if (count <= CONTIG_INLINE_TARGETS) {
-                d.target_offset = (int32_t)(c * row_words + (row_words - CONTIG_INLINE_TARGETS));
+                d.target_offset = (int32_t)(c * row_words + CONTIG_TARGETS_WORD);
                 for (int64_t i = 0; i < count; ++i) d.targets[i] = ht[first + i].entry;
                 continue;
             }
-#endif
             d.target_offset = (int32_t)(n_contigs * row_words + (int64_t)overflow.size());
             for (int64_t i = 0; i < count; ++i) overflow.push_back(ht[first + i].entry);
         }
@@ -544,6 +549,16 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                 ix->d.bucket_shift = (uint32_t)(32 - log2_buckets);
                 ix->bytes += (int64_t)n_buckets * (int64_t)sizeof(DevBucket);
                 ix->layout[0] = 1;
+                const char *no_succ = getenv("SKM_NO_SUCCESSORS");     // tuning aid: every junction k-mer looked up
+                if (successors_ok && !(no_succ && no_succ[0] == '1')) {
+                    // junction successors of every contig record (skm_device.h: DevContig), by the
+                    // lookup the kernels would do
+                    launch_successor_build(ix->d, (DevContig *)ix->contigs, n_contigs, nullptr);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipDeviceSynchronize());
+                    ix->d.successors = 1;
+                    ix->layout[6] = 1;
+                }
             } else {                 // not a set the reference's probe reaches everywhere: its layout decides
                 HIP_TRY(hipFree(ix->buckets));
                 ix->buckets = nullptr;
@@ -809,16 +824,25 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         // (wave borders in sixteenths of the batch; SKM_CLASS_WAVES="2,8" etc. is a tuning aid)
         int cuts[8] = {4, 16, 16, 16, 16, 16, 16, 16};
         int n_waves = two_waves && pass == 0 ? 2 : 1;
+#ifdef SKM_TUNING                                    // (tuning builds only: scripts/build_variant.sh)
         if (n_waves > 1)
             if (const char *e = getenv("SKM_CLASS_WAVES")) {
-                n_waves = 0;
-                for (const char *c = e; *c && n_waves < 7;) {
-                    cuts[n_waves++] = atoi(c);
+                int parsed[8], n = 0;
+                bool ok = true;
+                for (const char *c = e; *c && n < 7;) {
+                    parsed[n] = atoi(c);
+                    ok = ok && parsed[n] >= 1 && parsed[n] <= 16 && (n == 0 || parsed[n] > parsed[n - 1]);
+                    ++n;
                     while (*c && *c != ',') ++c;
                     if (*c == ',') ++c;
                 }
-                if (n_waves == 0 || cuts[n_waves - 1] < 16) cuts[n_waves++] = 16;
+                if (ok && n > 0) {                 // strictly ascending sixteenths, else ignored
+                    if (parsed[n - 1] < 16) parsed[n++] = 16;
+                    for (int i = 0; i < n; ++i) cuts[i] = parsed[i];
+                    n_waves = n;
+                }
             }
+#endif
         for (int wave = 0; wave < n_waves; ++wave) {
             const int64_t w0 = n_waves == 1 || wave == 0 ? 0 : n_units * cuts[wave - 1] / 16;
             const int64_t w1 = n_waves == 1 ? n_units : n_units * cuts[wave] / 16;
@@ -876,6 +900,8 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void **)&m->pinned, 64 * sizeof(unsigned long long)));
     if (const char *v = getenv("SKM_MAP_STATS")) m->want_stats = v[0] == '2' ? 2 : 1;
+    if (const char *v = getenv("SKM_TEST_PACKED_MAX_PENDING"))      // test hook: the pushers' byte limit
+        if (atoll(v) > 0) m->packed_max_pending = atoll(v);
     if (const char *v = getenv("SKM_MAP_VOTE"))          // tuning aid: "start,lookup,merge,left,right,emit,scan"
         sscanf(v, "%d,%d,%d,%d,%d,%d,%d", &m->vote[0], &m->vote[1], &m->vote[2], &m->vote[3], &m->vote[4],
                &m->vote[5], &m->vote[6]);
@@ -943,7 +969,6 @@ int run_job(skm_mapper *m, const skm_mapper::Job &job)
 // ---- packed pieces ----------------------------------------------------------------------
 constexpr int64_t PACKED_MIN_UNITS = 1 << 15;      // smaller runs wait for more (or for a flush)
 constexpr int64_t PACKED_MAX_UNITS = 1 << 21;      // one launch
-constexpr int64_t PACKED_MAX_PENDING = 8LL << 30;  // bytes of HBM that pieces may hold before a pusher waits
 
 // (q_mu held) the first run of units that every stream covers: [*lo, *hi), at most PACKED_MAX_UNITS
 bool packed_find_run(skm_mapper *m, int64_t *lo, int64_t *hi)
@@ -1060,7 +1085,10 @@ void worker_main(skm_mapper *m)
                     packed_drop_all(m);         // after a failure the table is not to be trusted
                     m->done_cv.notify_all();
                 }
-                if (packed_find_run(m, &lo, &hi) && (hi - lo >= PACKED_MIN_UNITS || m->packed_flush || m->stop)) {
+                // (a pusher that waits at the byte limit may be the only one who could make the run
+                // longer: its presence maps whatever run there is, as a flush does)
+                if (packed_find_run(m, &lo, &hi)
+                        && (hi - lo >= PACKED_MIN_UNITS || m->packed_flush || m->packed_waiters || m->stop)) {
                     packed = true;
                     break;
                 }
@@ -1106,7 +1134,12 @@ void worker_main(skm_mapper *m)
         std::string message;
         if (packed) {
             rc = run_packed_job(m, lo, hi, paired, segments, max_cw);
-            if (rc != SKM_OK) message = g_error;
+            if (rc != SKM_OK) {
+                message = g_error;
+                // kernels that read the pieces' blocks may still be queued: nothing is handed back
+                // to the pool (and from there to the next pusher's copy) before the stream has drained
+                (void)hipStreamSynchronize(m->stream);
+            }
             {
                 std::lock_guard<std::mutex> hold(m->q_mu);
                 if (rc != SKM_OK && m->job_error == SKM_OK) {
@@ -1257,6 +1290,26 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
     const int cw = piece->code_words;
     if (n < 0 || n >= (1LL << 31) || piece->first_read < 0) return fail(SKM_ERR_ARG, "bad piece: %lld reads from %lld", (long long)n, (long long)piece->first_read);
     if (piece->stream < 0 || piece->stream > (paired ? 1 : 0)) return fail(SKM_ERR_ARG, "stream %d of a %s sample", piece->stream, paired ? "paired" : "single-ended");
+    if (n == 0 && cw == SKM_PACKED_CUT) {
+        // a cut: the stream's reads from first_read on are dropped (the longer file of a pair of
+        // files, seekmer/common.py:180-197: zip() ends at the shorter one).  The run the worker may
+        // be mapping from the same piece ends where both streams had reads, i.e. at or below the cut.
+        std::unique_lock<std::mutex> hold(m->q_mu);
+        auto &list = m->pending[piece->stream];
+        const int64_t from = piece->first_read;
+        m->done_cv.wait(hold, [&] {
+            if (!m->packed_busy) return true;
+            for (const auto &other : list)
+                if (other.in_job && other.first + other.n > from) return false;
+            return true;
+        });
+        while (!list.empty() && list.back().first >= from) { m->packed_dropped += list.back().n; list.pop_back(); }
+        if (!list.empty() && list.back().first + list.back().n > from) {
+            m->packed_dropped += list.back().first + list.back().n - from;
+            list.back().n = from - list.back().first;
+        }
+        return SKM_OK;
+    }
     if (n == 0) return SKM_OK;
     if (cw < 1 || cw > (1 << 15) || piece->read_stride < cw || !piece->codes) return fail(SKM_ERR_ARG, "bad code words");
     if (piece->uniform_len < 0 && !piece->lengths) return fail(SKM_ERR_ARG, "lengths is NULL");
@@ -1284,11 +1337,17 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
     const int64_t block_bytes = (int64_t)(codes_bytes + len_bytes + exc_bytes + mask_bytes + 256);
     {
         std::unique_lock<std::mutex> hold(m->q_mu);
-        m->done_cv.wait(hold, [&] {
-            if (m->packed_bytes->load() + block_bytes <= PACKED_MAX_PENDING || m->job_error != SKM_OK) return true;
+        auto may_go = [&] {
+            if (m->packed_bytes->load() + block_bytes <= m->packed_max_pending || m->job_error != SKM_OK) return true;
             int64_t lo, hi;
             return !(m->packed_busy || packed_find_run(m, &lo, &hi));     // nothing the worker could free
-        });
+        };
+        if (!may_go()) {
+            m->packed_waiters++;                  // the worker now maps runs below PACKED_MIN_UNITS too
+            m->q_cv.notify_all();
+            m->done_cv.wait(hold, may_go);
+            m->packed_waiters--;
+        }
     }
     char *raw = nullptr;
     HIP_TRY(pool_alloc((void **)&raw, (size_t)block_bytes));
@@ -1320,20 +1379,36 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
     }
     HIP_TRY(hipStreamSynchronize(stream));        // (the caller's arrays are free again)
     {
-        std::lock_guard<std::mutex> hold(m->q_mu);
+        std::unique_lock<std::mutex> hold(m->q_mu);
         if (!m->worker_started) {
             m->worker = std::thread(worker_main, m);
             m->worker_started = true;
         }
         auto &list = m->pending[piece->stream];
         // a piece that overlaps what its stream holds replaces the reads from its first one on
-        bool overlaps = false;
-        for (const auto &other : list)
-            if (other.first < held.first + held.n && held.first < other.first + other.n) overlaps = true;
-        if (overlaps) {
+        auto overlapping = [&] {
             for (const auto &other : list)
-                if (other.in_job && other.first + other.n > held.first)
+                if (other.first < held.first + held.n && held.first < other.first + other.n) return true;
+            return false;
+        };
+        bool overlaps = overlapping();
+        if (overlaps) {
+            // a piece the worker is mapping from right now (the longer file of a pair of unequal
+            // length: its leftover reads are what this piece replaces): the run in flight ends where
+            // both streams had reads, so waiting for it leaves only the leftover to cut off -- the
+            // outcome does not depend on when the worker took the run
+            auto in_flight = [&] {
+                for (const auto &other : list)
+                    if (other.in_job && other.first + other.n > held.first) return true;
+                return false;
+            };
+            m->done_cv.wait(hold, [&] { return !m->packed_busy || !in_flight(); });
+            for (const auto &other : list)
+                if (other.first < held.first && other.first + other.n > held.first && other.in_job)
                     return fail(SKM_ERR_STATE, "a piece replaces reads that are being mapped");
+            overlaps = overlapping();
+        }
+        if (overlaps) {
             while (!list.empty() && list.back().first >= held.first) list.pop_back();
             if (!list.empty() && list.back().first + list.back().n > held.first) list.back().n = held.first - list.back().first;
             list.push_back(std::move(held));
@@ -1357,7 +1432,7 @@ extern "C" int skm_mapper_map_packed_source(skm_mapper *m, skm_packed_source nex
         memset(&piece, 0, sizeof(piece));
         const int rc = next(context, &piece);
         if (rc != SKM_OK) return fail(rc, "the source of packed reads failed (%d)", rc);
-        if (piece.n_reads == 0) return SKM_OK;
+        if (piece.n_reads == 0 && piece.code_words != SKM_PACKED_CUT) return SKM_OK;
         SKM_TRY(skm_mapper_push_packed(m, &piece, paired));
         if (n_pieces) ++*n_pieces;
     }

@@ -5,6 +5,7 @@
 // CDNA4 (64-wide waves, one unit per lane), not translated from the Cython.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace skm {
@@ -27,38 +28,43 @@ struct ContigEntry {                                             // _common.pxd:
 };
 
 // Contig record as the kernels read it.  The mapper runs at the chip's random sector-request
-// ceiling, so what counts is how many 64-byte sectors a contig visit touches -- and a visit that
-// merges or copies the contig's target list (KMerIndex.map_contig / _filter_on_contig,
-// _common.pyx:143-235) used to touch two, one after the other: the row, then the slice of
-// `targets` it points to.  The 48-byte reference row is therefore re-packed at upload to ONE
-// sector that carries the contig's first CONTIG_INLINE_TARGETS signed target entries behind the
-// row's fields (nine slices in ten have no more than eight): the row's target_offset points into
-// its own sector, the list arrives with the row, and a merge is one round trip instead of two.
-// Longer slices live behind the rows in the same allocation; `DevIndex::targets` addresses rows
-// and overflow alike as one int32 array (row c's inline entries are elements 16 c + 8 .. 16 c + 15).
-// SKM_CONTIG_INLINE=0 builds the former layout (32-byte rows, all slices in a separate array).
-#ifndef SKM_CONTIG_INLINE
-#define SKM_CONTIG_INLINE 1
-#endif
-#if SKM_CONTIG_INLINE
+// ceiling, so what counts is how many 64-byte sectors a contig visit touches and how many
+// DEPENDENT round trips a read needs.  The 48-byte reference row is therefore re-packed at upload
+// to a 128-byte record of two sectors:
+//   * sector 0, the row: the reference's fields and the contig's first CONTIG_INLINE_TARGETS
+//     signed target entries behind them (nine slices in ten have no more than eight): the row's
+//     target_offset points into its own sector, the list arrives with the row, and a merge
+//     (KMerIndex.map_contig / _filter_on_contig, _common.pyx:143-235) is one round trip instead
+//     of two.  Longer slices live behind the records in the same allocation; `DevIndex::targets`
+//     addresses records and overflow alike as one int32 array (row c's inline entries are
+//     elements 32 c + 8 .. 32 c + 15).
+//   * sector 1, the junction successors.  Every hop of _filter_targets_to_left/right
+//     (_mapper.pyx:246-248, :308-310) looks up ONE k-mer that is a pure function of (contig,
+//     end, orientation, read base): prepend / append of the anchor contig's edge k-mer
+//     (get_tail_kmer, _common.pyx:241-266) with the next base of the read.  There are eight such
+//     k-mers per contig -- `succ[b]` = map_kmer(append(tail k-mer at the contig's end, b)),
+//     `succ[4 + b]` = map_kmer(prepend(first_kmer, b)); an anchor on the reverse strand asks for
+//     the reverse complement of one of the same eight, whose answer is the stored one with the
+//     entry complemented (map_kmer, _common.pyx:84-87) -- so their map_kmer results are computed
+//     once at upload, with the device's own lookup, and a hop reads its answer from the record
+//     of the contig it is leaving: no visit to the k-mer table, one dependent round trip less
+//     per hop.  Stored exactly as map_kmer returns them (entries that hold a position with
+//     offset < 0 included: a stale anchor is part of the result); "not in the
+//     table" is SUCC_ABSENT, which no position of a validated index can be.
 constexpr int CONTIG_INLINE_TARGETS = 8;
-constexpr int CONTIG_SHIFT = 6;
-struct alignas(64) DevContig {
+constexpr int CONTIG_SHIFT = 7;
+constexpr int32_t SUCC_ABSENT = INT32_MIN;
+struct alignas(128) DevContig {
     int32_t offset, length;            // into the pooled bases
     int32_t target_offset, target_length;
     uint64_t first_kmer, last_kmer;
     int32_t targets[CONTIG_INLINE_TARGETS];
+    Coord succ[8];                     // [0..3] right of the contig's end, [4..7] left of its start
 };
-#else
-constexpr int CONTIG_INLINE_TARGETS = 0;
-constexpr int CONTIG_SHIFT = 5;
-struct alignas(32) DevContig {
-    int32_t offset, length;            // into the pooled bases
-    int32_t target_offset, target_length;
-    uint64_t first_kmer, last_kmer;
-};
-#endif
+constexpr int CONTIG_TARGETS_WORD = 8;      // offsetof(DevContig, targets) / 4
 static_assert(sizeof(DevContig) == (1u << CONTIG_SHIFT), "contig_at shifts by CONTIG_SHIFT");
+static_assert(offsetof(DevContig, targets) == 4 * CONTIG_TARGETS_WORD && offsetof(DevContig, succ) == 64,
+              "the row is sector 0, the successors sector 1");
 
 // The k-mer table as the mapper probes it.  The reference's table (linear
 // probing from a SipHash home slot, _common.pyx:54-97) is a set: a built index
@@ -100,6 +106,7 @@ struct DevIndex {
     int32_t max_target_count;
     int32_t edge_windows;      // first_kmer/last_kmer agree with the pooled bases on every contig
     int32_t sorted_targets;    // every contig's target slice ascends by signed entry (built indices do)
+    int32_t successors;        // every record carries its junction successors (see DevContig)
     const DevBucket *buckets;  // the same set of k-mers by bucket, or nullptr (see DevBucket)
     uint32_t bucket_mask;      // number of buckets - 1 (a power of two)
     uint32_t bucket_shift;     // bucket = bucket_hash(canonical k-mer) >> bucket_shift
@@ -255,23 +262,74 @@ __device__ __forceinline__ int bucket_find(const BucketKeys &k, uint64_t kmer, u
 }
 
 // map_kmer over the bucket table (same result as the probe above on every table that passed
-// skm_index_create's check)
-__device__ __forceinline__ Coord map_kmer_buckets(const DevIndex &ix, uint64_t kmer)
+// skm_index_create's check); `found` = the k-mer is in the table (whatever position it holds)
+__device__ __forceinline__ Coord map_kmer_buckets(const DevIndex &ix, uint64_t kmer, bool &found)
 {
     const uint64_t rc = kmer_revcomp(kmer);
     uint32_t b = bucket_hash(kmer < rc ? kmer : rc) >> ix.bucket_shift;
+    found = false;
     for (uint32_t n = 0; n <= ix.bucket_mask; ++n) {
         const BucketKeys keys = bucket_keys(ix, b);
         bool flip = false;
         const int j = bucket_find(keys, kmer, rc, flip);
         if (j >= 0) {
             const Coord c = bucket_at(ix, b)->pos[j];
+            found = true;
             return flip ? Coord{~c.entry, c.offset} : c;
         }
         if (j == -1) return invalid_coord();
         b = (b + 1) & ix.bucket_mask;
     }
     return invalid_coord();
+}
+__device__ __forceinline__ Coord map_kmer_buckets(const DevIndex &ix, uint64_t kmer)
+{
+    bool found;
+    return map_kmer_buckets(ix, kmer, found);
+}
+
+// The k-mer whose map_kmer result DevContig::succ[j] holds (see DevContig): the junction k-mers of
+// _filter_targets_to_right (j < 4: _kmer.append of the tail k-mer at the contig's end with base j,
+// _mapper.pyx:308-310) and of _filter_targets_to_left (j >= 4: _kmer.prepend of first_kmer with base
+// j - 4, :246-248) for an anchor on the forward strand.  get_tail_kmer (_common.pyx:241-266) tells
+// the two edge k-mers apart by `offset == 0`, so a contig of exactly k bases has first_kmer at its end too.
+__device__ __forceinline__ uint64_t successor_query(const DevContig &row, int j)
+{
+    const uint64_t tail_end = row.length == K ? row.first_kmer : row.last_kmer;
+    if (j < 4) return ((tail_end << 2) | (uint64_t)j) & KMER_MASK;
+    return (row.first_kmer >> 2) | ((uint64_t)(j - 4) << (2 * K - 2));
+}
+
+// map_kmer of the junction k-mer of a hop that leaves the anchor's contig: to the RIGHT
+// (append(get_tail_kmer(anchor), base), anchor on the contig's last k-mer in read direction) or to the
+// left (prepend(get_tail_kmer(anchor), base), anchor on its first).  A reverse anchor's k-mer is
+// the reverse complement of a forward one with the complementary base, and map_kmer of a reverse
+// complement is the same slot's position with the entry complemented.
+// The four candidates of a hop (32 bytes, half of the record's second sector) are requested when the
+// action starts, together with the row: which of them the hop takes is known only after the 8-base
+// alignment step, and a load issued then would be one more dependent round trip.
+struct SuccessorQuad { u32x4 lo, hi; };      // Coord 0 = lo.xy, 1 = lo.zw, 2 = hi.xy, 3 = hi.zw
+template <bool RIGHT>
+__device__ __forceinline__ SuccessorQuad load_successors(const DevIndex &ix, Coord anchor, bool wanted)
+{
+    SuccessorQuad q{{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (wanted) {
+        const bool forward = anchor.entry >= 0;
+        const int32_t index = forward ? anchor.entry : ~anchor.entry;
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(&contig_at(ix, index).succ[RIGHT == forward ? 0 : 4]);
+        q.lo = p[0];
+        q.hi = p[1];
+    }
+    return q;
+}
+__device__ __forceinline__ Coord junction_successor(const SuccessorQuad &q, Coord anchor, uint32_t base)
+{
+    const bool forward = anchor.entry >= 0;
+    const uint32_t b = forward ? base : 3u - base;
+    const uint32_t entry = b == 0 ? q.lo.x : b == 1 ? q.lo.z : b == 2 ? q.hi.x : q.hi.z;
+    const uint32_t offset = b == 0 ? q.lo.y : b == 1 ? q.lo.w : b == 2 ? q.hi.y : q.hi.w;
+    if ((int32_t)offset == SUCC_ABSENT) return invalid_coord();
+    return Coord{(int32_t)(forward ? entry : ~entry), (int32_t)offset};
 }
 
 // 32 consecutive 2-bit codes starting at base `p` of a packed array (first

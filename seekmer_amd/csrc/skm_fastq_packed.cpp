@@ -308,6 +308,12 @@ extern "C" int skm_fastq_packed_next(void *reader, skm_packed_reads *piece)
             const size_t f = (size_t)it.stream;
             int64_t units = q->file_reads[f];
             if (q->paired) units = std::min(units, q->file_reads[f + 1]);
+            // a stream that got more reads than that (the longer file) is cut back before anything
+            // of the next pair of files is handed out: its leftover reads must never meet the next
+            // file's reads of the other stream as their mates
+            int cut = -1;
+            for (int s = 0; q->paired && s < 2; ++s)
+                if (q->file_reads[f + (size_t)s] > units) cut = s;
             q->pair_base += units;
             q->stream_next[0] = q->stream_next[1] = q->pair_base;
             if (q->n_threads > 0) {
@@ -318,6 +324,12 @@ extern "C" int skm_fastq_packed_next(void *reader, skm_packed_reads *piece)
                 hold.unlock();
                 q->pcv.notify_all();
             } else q->next_deliver++;
+            if (cut >= 0) {
+                piece->stream = cut;
+                piece->code_words = SKM_PACKED_CUT;
+                piece->first_read = q->pair_base;
+                return SKM_OK;
+            }
             continue;
         }
         skm_fastq_packed::Result r;

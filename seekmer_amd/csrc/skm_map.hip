@@ -279,6 +279,21 @@ probe_check_kernel(DevIndex ix, uint64_t n_slots, unsigned long long *report)
     if (bad) atomicAdd(&report[3], bad);
 }
 
+// The junction successors of every contig record (DevContig::succ), by the device's own lookup over
+// the bucket table that has just passed its check: eight lanes per contig.
+__global__ void __launch_bounds__(256)
+successor_build_kernel(DevIndex ix, DevContig *records, int64_t n_contigs)
+{
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n_contigs * 8;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = g >> 3;
+        const int j = (int)(g & 7);
+        bool found;
+        const Coord pos = map_kmer_buckets(ix, successor_query(records[c], j), found);
+        records[c].succ[j] = found ? pos : Coord{0, SUCC_ABSENT};
+    }
+}
+
 // ------------------------------------------------------------------- mapper
 // Running target list of a context.  KMerIndex.map_contig (_common.pyx:143-179)
 // copies the first contig's target slice (reversed and complemented for a
@@ -700,6 +715,12 @@ enum : int { ST_IDLE = 0, ST_NEW,
              ST_HALF };                                // a mate that is done and waits for the other one
 enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_ACTIONS };
 constexpr int SCAN_ROUNDS = 4;
+#ifndef SKM_FUSE_MERGE
+#define SKM_FUSE_MERGE 0
+#endif
+#ifndef SKM_SUCC_EARLY
+#define SKM_SUCC_EARLY 1
+#endif
 
 constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
@@ -735,6 +756,9 @@ __global__ void __launch_bounds__(MAP_THREADS, SKM_MAP_WAVES_PER_EU)
 map_units_kernel(DevIndex ix, MapBatch b)
 {
     constexpr bool COUNT = STATS && !BUCKETS;
+    // junction lookups answered by the contig records (DevContig::succ; the counting build performs
+    // and counts the reference's lookups).  Uniform over the launch.
+    const bool SUCCESSORS = BUCKETS && ix.successors != 0;
     __shared__ uint32_t fld_lds[FLD_WINDOW];
     // contexts, structure of arrays
     __shared__ int32_t c_state[NCTX], c_unit[NCTX], c_begin[NCTX], c_end[NCTX], c_aentry[NCTX],
@@ -863,6 +887,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
             // load the context
             int word = valid ? c_state[c] : ST_IDLE;
             int state = word & 0xff, attempt = (word >> 9) & 1;
+            // the k-mer words hold the first hit's position while the left filter runs (see N_RIGHT_ENTER)
+            int first_hit_kept = (word >> 8) & 1;
             const int mate = b.paired ? (c & 1) : 0;
             const int64_t u = block_first + c_unit[c];
             Span span{c_begin[c], c_end[c], Coord{c_aentry[c], c_aoffset[c]}, (int32_t)((uint32_t)word >> 10)};
@@ -891,9 +917,26 @@ map_units_kernel(DevIndex ix, MapBatch b)
             };
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
+            // the alignment step a merge leads to, run by the same lane in the same round (SKM_FUSE_MERGE)
+            int then_step = -1;
+            if (valid && action == A_MERGE) {
+                // ---------------------------------- the one _filter_on_contig site
+                const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
+                if (state == M_LJ) {
+                    if (ok) state = N_LEFT;
+                    else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
+                } else if (state == M_LS) {
+                    if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
+                } else {
+                    if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
+                }
+                if (SKM_FUSE_MERGE && SUCCESSORS) then_step = state == N_LEFT ? A_LEFT : (state == N_RIGHT ? A_RIGHT : -1);
+            }
             if (valid && action == A_START) {
                 rv = read_view(block_records, b.record_words, b.words_per_read, first_read + (uint32_t)mate);
                 attempt = 0;
+                first_hit_kept = 0;
                 set.ext = mate ? ext2 : ext1;
                 set.start = 0; set.length = 0; set.word0 = 0;   // (a context starts with whatever LDS held)
                 span.begin = 0; span.end = 0; span.n = 0; span.anchor = invalid_coord();
@@ -918,6 +961,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         map_contig<STATS>(ix, pos, set, span, &ls);
                         state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
                         anchored = true;
+                        if (SUCCESSORS && state == N_LEFT) {
+                            kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
+                            first_hit_kept = 1;
+                        }
                     } else if (scan_i < rv.len) {
                         kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;   // _kmer.append
                         ++scan_i;
@@ -932,7 +979,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     state = state == Y_LJ ? M_LJ : (state == Y_LS ? M_LS : M_RJ);
                 } else if (state == Y_LJ) {                   // miss at the junction, :250-259
                     if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
-                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
+                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
                 } else {                                      // Y_LS :260-263, Y_RJ :312-315
                     span.n = 0;
                     state = N_AFTER;
@@ -990,6 +1037,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     map_contig<STATS>(ix, pos, set, span, &ls);
                     state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
                     anchored = true;
+                    if (SUCCESSORS && state == N_LEFT) {
+                        kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
+                        first_hit_kept = 1;
+                    }
                 } else if (scan_i < rv.len) {
                     if ((scan_i >> 4) != ((scan_i - last) >> 4)) look = read_half(rv, scan_i >> 4);
                     kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
@@ -1009,6 +1060,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         map_contig<STATS>(ix, pos, set, span, &ls);
                         state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
                         anchored = true;
+                        if (SUCCESSORS && state == N_LEFT) {
+                            kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
+                            first_hit_kept = 1;
+                        }
                     } else if (scan_i < rv.len) {
                         kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
                         ++scan_i;
@@ -1017,21 +1072,13 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         state = N_MATE_DONE;
                     }
                 }
-            } else if (valid && action == A_MERGE) {
-                // ---------------------------------- the one _filter_on_contig site
-                const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
-                if (state == M_LJ) {
-                    if (ok) state = N_LEFT;
-                    else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
-                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; }
-                } else if (state == M_LS) {
-                    if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
-                } else {
-                    if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
-                }
-            } else if (valid && action == A_LEFT) {
+            } else if (valid && (action == A_LEFT || then_step == A_LEFT)) {
                 // --------------- _filter_targets_to_left: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
+                // (a forward anchor's distance to the contig's left edge is its offset: whether this
+                // is a hop is then known before the row arrives, and a closing check asks for no successors)
+                SuccessorQuad next = load_successors<false>(ix, span.anchor, SKM_SUCC_EARLY && SUCCESSORS
+                                                            && (!forward || span.begin > span.anchor.offset));
                 const int move = left_move(ix, span.anchor);
                 if (STATS) ls.contig_reads++;
                 const bool in_loop = span.begin > move;
@@ -1059,18 +1106,28 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     if (span.begin < 0) {
                         span.begin = 0;
                         state = N_RIGHT_ENTER;
+                    } else if (SUCCESSORS) {
+                        // the junction lookup (:247-249), answered by the record of the contig the hop
+                        // leaves: what A_LOOKUP does for Y_LJ, without the visit to the k-mer table
+                        if (!SKM_SUCC_EARLY) next = load_successors<false>(ix, span.anchor, true);
+                        span.anchor = junction_successor(next, span.anchor, read_code(rv, span.begin));
+                        if (span.anchor.offset >= 0) state = M_LJ;
+                        else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }     // :250-259
+                        else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
                     } else {
                         kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)          // _kmer.prepend
                                | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
                         state = Y_LJ;
                     }
                 }
-            } else if (valid && action == A_RIGHT) {
+            } else if (valid && (action == A_RIGHT || then_step == A_RIGHT)) {
                 // -------------- _filter_targets_to_right: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
+                const int rest = rv.len - span.end - K;
+                SuccessorQuad next = load_successors<true>(ix, span.anchor, SKM_SUCC_EARLY && SUCCESSORS
+                                                           && (forward || rest > span.anchor.offset));
                 const int move = right_move(ix, span.anchor);
                 if (STATS) ls.contig_reads++;
-                const int rest = rv.len - span.end - K;
                 const bool in_loop = rest > move;
                 int at;
                 if (in_loop) {
@@ -1096,6 +1153,12 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     if (span.end + K > rv.len) {
                         span.end = rv.len - K;
                         state = N_AFTER;
+                    } else if (SUCCESSORS) {
+                        // the junction lookup (:309-311) from the record: Y_RJ's part of A_LOOKUP
+                        if (!SKM_SUCC_EARLY) next = load_successors<true>(ix, span.anchor, true);
+                        span.anchor = junction_successor(next, span.anchor, read_code(rv, span.end + K - 1));
+                        if (span.anchor.offset >= 0) state = M_RJ;
+                        else { span.n = 0; state = N_AFTER; }                                    // :312-315
                     } else {
                         kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)          // _kmer.append
                                 | read_code(rv, span.end + K - 1)) & KMER_MASK;
@@ -1249,6 +1312,14 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         // result, so the repeat is skipped (the counting build performs it).
                         if (anchored && !COUNT) {
                             state = N_RIGHT;
+                        } else if (first_hit_kept && !COUNT) {
+                            // after a left filter the k-mer at span.end is still the first hit (the
+                            // filter moves span.begin only), whose position was kept in the k-mer
+                            // words: they were free, the junction lookups of a record-answered hop
+                            // need no k-mer (a skip-a-k lookup, :257-263, takes them back)
+                            span.anchor = Coord{(int32_t)(uint32_t)kmer, (int32_t)(uint32_t)(kmer >> 32)};
+                            first_hit_kept = 0;
+                            state = N_RIGHT;
                         } else {
                             kmer = read_kmer(rv, span.end);
                             state = Y_RA;
@@ -1261,6 +1332,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         state = N_MATE_DONE;
                     } else {                                  // the single retry, :179-185
                         attempt = 1;
+                        first_hit_kept = 0;
                         span.anchor = invalid_coord();
                         span.begin += K;
                         if (span.begin + K > rv.len) span.begin = rv.len - K;
@@ -1277,7 +1349,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
 
             // store the context
             if (valid && action != A_EMIT) {
-                c_state[c] = (int32_t)((uint32_t)state | ((uint32_t)attempt << 9) | ((uint32_t)span.n << 10));
+                c_state[c] = (int32_t)((uint32_t)state | ((uint32_t)first_hit_kept << 8) | ((uint32_t)attempt << 9)
+                                       | ((uint32_t)span.n << 10));
                 c_begin[c] = span.begin;
                 c_end[c] = span.end;
                 c_aentry[c] = span.anchor.entry;
@@ -1371,6 +1444,11 @@ void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *bucket
     hipLaunchKernelGGL(bucket_fill_kernel, dim3(4096), dim3(256), 0, stream, ix.kmers, n_slots, buckets,
                        bucket_mask, bucket_shift, report);
     hipLaunchKernelGGL(probe_check_kernel, dim3(4096), dim3(256), 0, stream, ix, n_slots, report);
+}
+
+void launch_successor_build(const DevIndex &ix, DevContig *records, int64_t n_contigs, hipStream_t stream)
+{
+    hipLaunchKernelGGL(successor_build_kernel, dim3(2048), dim3(256), 0, stream, ix, records, n_contigs);
 }
 
 void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,

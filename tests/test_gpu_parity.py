@@ -1428,3 +1428,57 @@ def test_packed_reads_give_the_same_tables(oracle, native_libs, chr21, chr21_ora
         for piece in streams:
             rm.push_packed(piece)
         same(one)
+
+
+def test_pairs_of_files_of_unequal_length_and_a_pusher_at_the_byte_limit(oracle, native_libs, chr21, chr21_oracle_index,
+                                                                         tmp_path, monkeypatch):
+    """Two things the packed path must get right whatever the timing.
+    (a) Several pairs of FASTQ files where a mate-2 file is the longer one: zip(file1, file2)
+        (seekmer/common.py:180-197) ends at the shorter file, so the longer file's leftover reads must be
+        cut off before the next pair of files delivers reads of the other stream -- they would meet as
+        mates otherwise.  The one-pass reader sends a cut (SKM_PACKED_CUT) first; the table is the one of
+        the Python feeders' batches, natively drained and piece by piece, for every chunk size.
+    (b) A pusher that is held back by the byte limit while the only mappable run is shorter than the
+        worker's minimum: the run is mapped (nobody else could extend it) instead of everyone waiting."""
+    from seekmer_amd import common, mapper
+    rng = np.random.default_rng(5)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    reads = _adversarial_reads(chr21[1], rng, 2 * 4000, 100)
+    sizes = [(1500, 1700), (900, 600), (1000, 1300)]            # records of (mate 1 file, mate 2 file) per pair of files
+    files, kept, at = [], [], 0
+    for k, (n1, n2) in enumerate(sizes):
+        for s, n in enumerate((n1, n2)):
+            path = tmp_path / ('p%d_%d.fastq' % (k, s + 1))
+            with open(path, 'wb') as f:
+                for u in range(n):
+                    read = reads[2 * (at + u) + s]
+                    f.write(b'@r%d\n' % u + read + b'\n+\n' + b'I' * len(read) + b'\n')
+            files.append(path)
+        for u in range(min(n1, n2)):
+            kept += [reads[2 * (at + u)], reads[2 * (at + u) + 1]]
+        at += max(n1, n2)
+    n_units = len(kept) // 2
+    bases, offsets = oracle.pack_reads(kept)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, True, fld)
+    for threads, chunk in ((0, 0), (3, 20_000), (2, 150_000)):
+        drained = mapper.map_reads(index, common.PackedReadFeeder(files, True, threads=threads, chunk_bytes=chunk), job_count=1)
+        _compare_tables(oracle, expected, fld, drained)
+        stepwise = mapper.MapResult(index)
+        mapper.ReadMapper(index, stepwise)(common.PackedReadFeeder(files, True, threads=threads, chunk_bytes=chunk))
+        _compare_tables(oracle, expected, fld, stepwise)
+    # the Python feeders agree (they are the reference's zip)
+    python_fed = mapper.map_reads(index, common.feed_pair_ended_reads(*files), job_count=1)
+    _compare_tables(oracle, expected, fld, python_fed)
+
+    # (b) 2 KB of pieces may wait; mate 2 delivers 50 reads, then mate 1 everything, then mate 2 the rest
+    monkeypatch.setenv('SKM_TEST_PACKED_MAX_PENDING', '2048')
+    limited = mapper.MapResult(index)
+    rm = mapper.ReadMapper(index, limited)
+    streams = _streams_of(common, bases, offsets, n_units, True)
+    head, tail = _cut(common, streams[1], [0, 50, n_units])
+    rm.push_packed(head)
+    for piece in _cut(common, streams[0], list(range(0, n_units, 400)) + [n_units]):
+        rm.push_packed(piece)                 # (hung here before: 50 < PACKED_MIN_UNITS and nobody flushing)
+    rm.push_packed(tail)
+    _compare_tables(oracle, expected, fld, limited)

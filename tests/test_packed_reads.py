@@ -35,6 +35,9 @@ def assemble(pieces, n_streams):
         s = piece.stream
         for r in [r for r in streams[s] if r >= piece.first_read]:
             del streams[s][r]
+        if piece.is_cut:                  # (the longer mate-2 file of a pair of files, cut back)
+            ends[s] = piece.first_read
+            continue
         codes, lengths = piece.codes, piece.lengths
         exc_reads, exc_masks = piece.exceptions
         exc = {int(r): exc_masks[k] for k, r in enumerate(exc_reads)}
