@@ -140,6 +140,10 @@ int skm_mapper_map_batch_async(skm_mapper *mapper, const char *bases,
 int skm_mapper_map_batch_uniform_async(skm_mapper *mapper, const char *bases, int32_t read_len,
                                        int64_t n_units, int paired, int64_t first_unit);
 int skm_mapper_sync(skm_mapper *mapper);
+/* An optional hint before a sample's reads arrive: about this many units will be mapped (a reader
+ * knows its files' sizes).  The class table and the batch buffers are then sized once instead of
+ * growing under the sample's first launches; results do not depend on it. */
+int skm_mapper_expect_units(skm_mapper *mapper, int64_t n_units);
 /* Reads packed on the host.
  * The mapper works on 2-bit codes and one "is an upper-case ACGT" bit per base
  * (seekmer/_kmer.pxd:253-273, seekmer/_mapper.pyx:500-501); in FASTQ text nearly every read has all
@@ -216,6 +220,27 @@ int skm_mapper_merge(skm_mapper *mapper, int64_t n_classes,
                      const int64_t *class_offsets, const int32_t *class_targets,
                      const int64_t *class_counts, const int64_t *first_seen,
                      int64_t unaligned, const int64_t *fld);
+/* The same hand-over without the host: a mapper's table where it lies in HBM --
+ * classes in registry order (any order: the merge is by key, first-seen values travel with the
+ * classes), class c = ids[class_start[c] .. + class_len[c]) (unsigned ids, tuple order), counts as
+ * doubles, plus the unit totals and the histogram -- and its merge into a mapper ON THE SAME GPU.
+ * Between GPUs the arrays are first copied over xGMI (ncclSend / ncclRecv or a peer copy: n_classes
+ * elements of class_start / class_len / class_count / first_seen, n_ids of ids, 2000 of fld) and the
+ * struct re-pointed at the copies.  The pointers of skm_mapper_device_table stay valid until the
+ * mapper maps, merges, resets or is destroyed. */
+typedef struct skm_device_table {
+    int32_t device;
+    int64_t n_classes, n_ids;
+    const int64_t *class_start;      /* [n_classes] into ids */
+    const int64_t *class_len;        /* [n_classes] */
+    const double *class_count;       /* [n_classes] */
+    const uint64_t *first_seen;      /* [n_classes] global unit index of the class's first unit */
+    const int32_t *ids;              /* [n_ids] */
+    int64_t unaligned, units, first_seen_bound;
+    const uint64_t *fld;             /* [2000] */
+} skm_device_table;
+int skm_mapper_device_table(skm_mapper *mapper, skm_device_table *out);
+int skm_mapper_merge_device(skm_mapper *mapper, const skm_device_table *table);
 int skm_mapper_clear(skm_mapper *mapper);           /* MapResult.clear, mapper.py:143-145 */
 /* Back to the state of a fresh MapResult (counter, unit count AND histogram
  * zeroed) while keeping every HBM buffer allocated. */
@@ -391,6 +416,9 @@ int skm_fastq_packed_next(void *reader, skm_packed_reads *piece);
  * [4]=parser variant in use (0 single characters, 1 16-byte blocks, 2 32-byte blocks)
  * [5]=units of the sample so far (paired: min over the two streams, per pair of files) */
 int skm_fastq_packed_stats(const skm_fastq_packed *reader, int64_t stats[8]);
+/* About how many units the files hold (each mate-1 / single-end file's size over the extent of its
+ * first record): the hint for skm_mapper_expect_units. */
+int skm_fastq_packed_estimate(const skm_fastq_packed *reader, int64_t *units);
 int skm_fastq_packed_close(skm_fastq_packed *reader);
 /* The same packing for reads that are already in memory (bases back to back + offsets, the layout
  * of skm_mapper_map_batch): codes[n_reads][code_words], lengths[n_reads]; exception arrays hold up

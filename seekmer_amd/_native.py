@@ -39,6 +39,14 @@ class PackedReads(ctypes.Structure):
                 ('names', ctypes.c_void_p), ('name_offsets', ctypes.c_void_p)]
 
 
+class DeviceTable(ctypes.Structure):
+    """skm_device_table (include/seekmer_hip.h): a mapper's class table where it lies in HBM"""
+    _fields_ = [('device', ctypes.c_int32), ('n_classes', ctypes.c_int64), ('n_ids', ctypes.c_int64),
+                ('class_start', ctypes.c_void_p), ('class_len', ctypes.c_void_p), ('class_count', ctypes.c_void_p),
+                ('first_seen', ctypes.c_void_p), ('ids', ctypes.c_void_p), ('unaligned', ctypes.c_int64),
+                ('units', ctypes.c_int64), ('first_seen_bound', ctypes.c_int64), ('fld', ctypes.c_void_p)]
+
+
 # every symbol include/seekmer_hip.h declares, by library
 HIP_SYMBOLS = {
     'skm_last_error': (ctypes.c_char_p, []),
@@ -68,6 +76,7 @@ HIP_SYMBOLS = {
     'skm_mapper_map_batch_uniform_async': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, c_i64,
                                                           ctypes.c_int, c_i64]),
     'skm_mapper_sync': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_mapper_expect_units': (ctypes.c_int, [ctypes.c_void_p, c_i64]),
     'skm_mapper_push_packed': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PackedReads), ctypes.c_int]),
     'skm_mapper_map_packed_source': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                     c_i64p]),
@@ -81,6 +90,8 @@ HIP_SYMBOLS = {
     'skm_mapper_export': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_i32p, c_i64p, c_i64p, c_i64p]),
     'skm_mapper_merge': (ctypes.c_int, [ctypes.c_void_p, c_i64, c_i64p, c_i32p, c_i64p, c_i64p,
                                         c_i64, c_i64p]),
+    'skm_mapper_device_table': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(DeviceTable)]),
+    'skm_mapper_merge_device': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(DeviceTable)]),
     'skm_mapper_clear': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_reset': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_mapper_timing': (ctypes.c_int, [ctypes.c_void_p, c_f64p]),
@@ -138,6 +149,7 @@ HOST_SYMBOLS = {
     'skm_fastq_packed_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_packed_next': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PackedReads)]),
     'skm_fastq_packed_stats': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
+    'skm_fastq_packed_estimate': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_fastq_packed_close': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_pack_reads': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_i64, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64p,

@@ -647,6 +647,13 @@ class _PackedReader:
             return None
         return PackedReads(raw, keep=self, paired=self.paired)       # (a piece or a cut)
 
+    def estimate(self):
+        """About how many units the files hold (file size over the first record's extent)."""
+        units = ctypes.c_int64()
+        _native.check_host(_native.host().skm_fastq_packed_estimate(self.handle, ctypes.byref(units)),
+                           'skm_fastq_packed_estimate')
+        return units.value
+
     def stats(self):
         out = (ctypes.c_int64 * 8)()
         _native.check_host(_native.host().skm_fastq_packed_stats(self.handle, out), 'skm_fastq_packed_stats')

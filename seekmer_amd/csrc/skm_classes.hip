@@ -387,16 +387,20 @@ class_compact_kernel(ClassTable t, int64_t n_classes, int64_t *cls_offset, int64
     }
 }
 
-// Counter.update with a foreign table (another GPU's export)
+// Counter.update with a foreign table (another GPU's export).  The foreign classes come either as
+// the arrays of skm_mapper_export (CSR offsets, int64 counts; class_len == nullptr) or as they lie in
+// another mapper's HBM (skm_device_table: class c = ids[class_offsets[c] .. + class_len[c]), counts
+// as doubles, registry order).
+template <typename Count>
 __global__ void __launch_bounds__(256)
-class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets,
-                   const int32_t *class_targets, const int64_t *class_counts,
+class_merge_kernel(ClassTable t, int64_t n_classes, const int64_t *class_offsets, const int64_t *class_len,
+                   const int32_t *class_targets, const Count *class_counts,
                    const int64_t *first_seen)
 {
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_classes;
          c += (int64_t)gridDim.x * blockDim.x) {
         const int64_t off = class_offsets[c];
-        const int n = (int)(class_offsets[c + 1] - off);
+        const int n = (int)(class_len ? class_len[c] : class_offsets[c + 1] - off);
         unsigned long long key = 0x243F6A8885A308D3ULL ^ (unsigned long long)n;
         for (int i = 0; i < n; ++i) {
             key ^= (uint32_t)class_targets[off + i];
@@ -510,9 +514,38 @@ void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *c
                         const int64_t *first_seen, hipStream_t stream)
 {
     if (n_classes == 0) return;
-    hipLaunchKernelGGL(class_merge_kernel, dim3(grid_for(n_classes)), dim3(256), 0, stream, t,
-                       n_classes, class_offsets, class_targets, class_counts, first_seen);
+    hipLaunchKernelGGL(class_merge_kernel<int64_t>, dim3(grid_for(n_classes)), dim3(256), 0, stream, t,
+                       n_classes, class_offsets, (const int64_t *)nullptr, class_targets, class_counts, first_seen);
     hipLaunchKernelGGL(class_totals_kernel, dim3(1), dim3(64), 0, stream, t, (const unsigned long long *)nullptr);
+}
+
+// the unit totals and the histogram of a foreign table, added on the device
+__global__ void __launch_bounds__(256)
+class_add_totals_kernel(ClassTable t, unsigned long long unaligned, unsigned long long units,
+                        const unsigned long long *fld)
+{
+    if (threadIdx.x == 0) { *t.n_unaligned += unaligned; *t.n_units += units; }
+    if (fld)
+        for (int i = threadIdx.x; i < MAX_FRAGMENT_LENGTH; i += blockDim.x) t.global_fld[i] += fld[i];
+}
+
+void launch_class_merge_device(const ClassTable &t, int64_t n_classes, const int64_t *class_start,
+                               const int64_t *class_len, const int32_t *ids, const double *class_counts,
+                               const unsigned long long *first_seen, unsigned long long unaligned,
+                               unsigned long long units, const unsigned long long *fld, hipStream_t stream)
+{
+    if (n_classes) {
+        hipLaunchKernelGGL(class_merge_kernel<double>, dim3(grid_for(n_classes)), dim3(256), 0, stream, t,
+                           n_classes, class_start, class_len, ids, class_counts, (const int64_t *)first_seen);
+        hipLaunchKernelGGL(class_totals_kernel, dim3(1), dim3(64), 0, stream, t, (const unsigned long long *)nullptr);
+    }
+    hipLaunchKernelGGL(class_add_totals_kernel, dim3(1), dim3(256), 0, stream, t, unaligned, units, fld);
+}
+
+void warm_code_classes()
+{
+    hipFuncAttributes attributes;
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&class_insert_kernel));
 }
 
 }  // namespace skm

@@ -821,6 +821,12 @@ void launch_pack_sequences(const char *bases, int64_t n_bases, uint64_t *seq2, i
                        n_bases, seq2, n_words);
 }
 
+void warm_code_em()
+{
+    hipFuncAttributes attributes;
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&em_inner_kernel));
+}
+
 }  // namespace skm
 
 // ------------------------------------------------------------ diagnostics

@@ -366,4 +366,12 @@ void launch_em_batch_ctl(unsigned long long *ctl, unsigned int idle, hipStream_t
     hipLaunchKernelGGL(em_batch_ctl_kernel, dim3(1), dim3(64), 0, stream, ctl, idle);
 }
 
+// (skm_index_create loads every code object of the library before the first sample needs it: the first
+// launch out of a translation unit otherwise pays its load, tens of milliseconds, inside the run)
+void warm_code_em_batch()
+{
+    hipFuncAttributes attributes;
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&em_inner_batch_kernel));
+}
+
 }  // namespace skm

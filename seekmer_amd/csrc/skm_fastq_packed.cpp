@@ -404,6 +404,24 @@ extern "C" int skm_fastq_packed_stats(const skm_fastq_packed *q, int64_t stats[8
     return SKM_OK;
 }
 
+// About how many units the files hold: each mate-1 (or single-end) file's size over the extent of its
+// first record.  A hint for whoever sizes tables before the reads arrive (skm_mapper_expect_units).
+extern "C" int skm_fastq_packed_estimate(const skm_fastq_packed *q, int64_t *units)
+{
+    if (!q || !units) return SKM_ERR_ARG;
+    int64_t total = 0;
+    const size_t step = q->paired ? 2 : 1;
+    for (size_t f = 0; f < q->files.size(); f += step) {
+        const Mapped &m = q->files[f];
+        size_t at = 0;
+        for (int line = 0; line < 4 && at < m.n; ++line) at = next_newline(m.p, m.n, at) + 1;
+        if (at > m.n) at = m.n;
+        if (at) total += (int64_t)((m.n + at - 1) / at);
+    }
+    *units = total;
+    return SKM_OK;
+}
+
 extern "C" int skm_fastq_packed_close(skm_fastq_packed *q)
 {
     delete q;

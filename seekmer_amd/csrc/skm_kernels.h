@@ -125,6 +125,13 @@ void launch_class_merge(const ClassTable &t, int64_t n_classes, const int64_t *c
                         const int32_t *class_targets, const int64_t *class_counts,
                         const int64_t *first_seen, hipStream_t stream);
 
+// the same with the foreign table in HBM as class_compact leaves it (registry order, counts as
+// doubles) + its unit totals and histogram: nothing crosses the host
+void launch_class_merge_device(const ClassTable &t, int64_t n_classes, const int64_t *class_start,
+                               const int64_t *class_len, const int32_t *ids, const double *class_counts,
+                               const unsigned long long *first_seen, unsigned long long unaligned,
+                               unsigned long long units, const unsigned long long *fld, hipStream_t stream);
+
 // ---- quantification (skm_em.hip, skm_quant_setup.hip)
 constexpr int EM_ROW_CAP = 512;   // longest run of one transcript's classes summed by one lane group
 
@@ -226,6 +233,7 @@ int64_t quant_setup(const ClassTable *table, QuantBuild &q, int32_t *perm, hipSt
 // y[k] = x[perm[k]] (gather) or y[perm[k]] = x[k] (scatter), n doubles
 void launch_permute_f64(const double *x, const int32_t *perm, int64_t n, double *y, bool scatter,
                         hipStream_t stream);
+const char *quant_setup_failure();       // what made the last quant_setup of this thread return < 0
 int64_t quant_rows_upper_bound(int64_t n_tx, int64_t n_ids);
 
 // numpy.sum(a) bit for bit -> out[0], out[1] = out[0] / divisor; block_sums: ceil(n/8192) doubles
@@ -250,5 +258,12 @@ bool launch_multinomial(const unsigned long long *cum, int64_t n_classes, int64_
                         int stride, hipStream_t stream);
 void launch_u64_to_double(const unsigned long long *in, int64_t n, double *out, hipStream_t stream);
 void launch_double_to_u64(const double *in, int64_t n, unsigned long long *out, hipStream_t stream);
+
+// one hipFuncGetAttributes per translation unit: its code object is loaded now, not by a sample's first launch
+void warm_code_map();
+void warm_code_classes();
+void warm_code_em();
+void warm_code_em_batch();
+void warm_code_quant_setup();
 
 }  // namespace skm

@@ -408,17 +408,18 @@ __device__ __forceinline__ void load_list(const DevIndex &ix, int32_t start, int
 // positions of `a` (ascending, NO_ENTRY = absent) that a two-pointer walk against the
 // multiset `b` (NO_ENTRY_B = absent) keeps: the r-th copy of a value survives iff b holds more
 // than r copies
-__device__ __forceinline__ uint32_t keep_common_exact(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS])
+template <int N>
+__device__ __forceinline__ uint32_t keep_common_exact(const int32_t (&a)[N], const int32_t (&b)[N])
 {
     uint32_t keep = 0;
     int32_t prev = NO_ENTRY;
     int run = 0;
 #pragma unroll
-    for (int i = 0; i < LIST_REGS; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int32_t v = a[i];
         int copies = 0;
 #pragma unroll
-        for (int j = 0; j < LIST_REGS; ++j) copies += (b[j] == v) ? 1 : 0;
+        for (int j = 0; j < N; ++j) copies += (b[j] == v) ? 1 : 0;
         const bool present = v != NO_ENTRY;
         run = (present && v == prev) ? run + 1 : (present ? 0 : run);
         if (present) prev = v;
@@ -431,20 +432,20 @@ __device__ __forceinline__ uint32_t keep_common_exact(const int32_t (&a)[LIST_RE
 // the smallest a[i] ^ b[j] over j is 0 iff a[i] is in b -- v_xor + half a v_min3_u32 per pair,
 // no lane masks through scalar registers (compare + s_or was two instructions per pair and
 // compare + add-with-carry costs two wait states per pair on gfx950).
-__device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[LIST_REGS], const int32_t (&b)[LIST_REGS],
-                                                bool twice)
+template <int N>
+__device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[N], const int32_t (&b)[N], bool twice)
 {
-    if (twice) return keep_common_exact(a, b);
+    if (twice) return keep_common_exact<N>(a, b);
     uint32_t dropped = 0;
 #pragma unroll
-    for (int i = 0; i < LIST_REGS; ++i) {
+    for (int i = 0; i < N; ++i) {
         uint32_t nearest = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < LIST_REGS; j += 2)
+        for (int j = 0; j < N; j += 2)
             nearest = min(nearest, min((uint32_t)(a[i] ^ b[j]), (uint32_t)(a[i] ^ b[j + 1])));
         dropped |= min(nearest, 1u) << i;                 // 1 = a[i] is not in b
     }
-    return ~dropped & LIST_ALL;
+    return ~dropped & ((1u << N) - 1u);
 }
 
 // KMerIndex._filter_on_contig, _common.pyx:185-235: two-pointer merge of the
@@ -466,7 +467,7 @@ __device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, 
         bool twice_a, twice_t;
         load_list(ix, set.start, set.length, set.forward, (uint32_t)set.word0, NO_ENTRY, a, twice_a);
         load_list(ix, start, length, forward, LIST_ALL, NO_ENTRY_B, t, twice_t);   // (order within the slice is immaterial)
-        const uint32_t keep = keep_common(a, t, twice_a | twice_t);
+        const uint32_t keep = keep_common<LIST_REGS>(a, t, twice_a | twice_t);
         if (keep == 0) return false;
         set.word0 = keep;
         span.n = __builtin_popcount(keep);
@@ -625,7 +626,7 @@ __device__ __forceinline__ bool intersect(const DevIndex &ix, TSet &a, Span &s1,
         // yields exactly that at mirrored positions, and positions do not matter on this side.
         const uint32_t mirrored = __brev((uint32_t)b2.word0) >> (32 - b2.length);
         load_list(ix, b2.start, b2.length, !b2.forward, mirrored, NO_ENTRY_B, e2, twice2);
-        const uint32_t keep = keep_common(e1, e2, twice1 | twice2);
+        const uint32_t keep = keep_common<LIST_REGS>(e1, e2, twice1 | twice2);
         a.word0 = keep;
         if (keep == 0) return false;
         s1.n = __builtin_popcount(keep);
@@ -715,12 +716,7 @@ enum : int { ST_IDLE = 0, ST_NEW,
              ST_HALF };                                // a mate that is done and waits for the other one
 enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_ACTIONS };
 constexpr int SCAN_ROUNDS = 4;
-#ifndef SKM_FUSE_MERGE
-#define SKM_FUSE_MERGE 0
-#endif
-#ifndef SKM_SUCC_EARLY
-#define SKM_SUCC_EARLY 1
-#endif
+
 
 constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
 constexpr int ARENA_CHUNK = 2048;     // ids a wave takes from the entry arena per atomic
@@ -917,8 +913,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
             };
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
-            // the alignment step a merge leads to, run by the same lane in the same round (SKM_FUSE_MERGE)
-            int then_step = -1;
             if (valid && action == A_MERGE) {
                 // ---------------------------------- the one _filter_on_contig site
                 const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
@@ -931,7 +925,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 } else {
                     if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
                 }
-                if (SKM_FUSE_MERGE && SUCCESSORS) then_step = state == N_LEFT ? A_LEFT : (state == N_RIGHT ? A_RIGHT : -1);
             }
             if (valid && action == A_START) {
                 rv = read_view(block_records, b.record_words, b.words_per_read, first_read + (uint32_t)mate);
@@ -1072,13 +1065,13 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         state = N_MATE_DONE;
                     }
                 }
-            } else if (valid && (action == A_LEFT || then_step == A_LEFT)) {
+            } else if (valid && action == A_LEFT) {
                 // --------------- _filter_targets_to_left: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
                 // (a forward anchor's distance to the contig's left edge is its offset: whether this
                 // is a hop is then known before the row arrives, and a closing check asks for no successors)
-                SuccessorQuad next = load_successors<false>(ix, span.anchor, SKM_SUCC_EARLY && SUCCESSORS
-                                                            && (!forward || span.begin > span.anchor.offset));
+                const SuccessorQuad next = load_successors<false>(ix, span.anchor,
+                                                                  SUCCESSORS && (!forward || span.begin > span.anchor.offset));
                 const int move = left_move(ix, span.anchor);
                 if (STATS) ls.contig_reads++;
                 const bool in_loop = span.begin > move;
@@ -1109,7 +1102,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     } else if (SUCCESSORS) {
                         // the junction lookup (:247-249), answered by the record of the contig the hop
                         // leaves: what A_LOOKUP does for Y_LJ, without the visit to the k-mer table
-                        if (!SKM_SUCC_EARLY) next = load_successors<false>(ix, span.anchor, true);
                         span.anchor = junction_successor(next, span.anchor, read_code(rv, span.begin));
                         if (span.anchor.offset >= 0) state = M_LJ;
                         else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }     // :250-259
@@ -1120,12 +1112,12 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         state = Y_LJ;
                     }
                 }
-            } else if (valid && (action == A_RIGHT || then_step == A_RIGHT)) {
+            } else if (valid && action == A_RIGHT) {
                 // -------------- _filter_targets_to_right: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
                 const int rest = rv.len - span.end - K;
-                SuccessorQuad next = load_successors<true>(ix, span.anchor, SKM_SUCC_EARLY && SUCCESSORS
-                                                           && (forward || rest > span.anchor.offset));
+                const SuccessorQuad next = load_successors<true>(ix, span.anchor,
+                                                                 SUCCESSORS && (forward || rest > span.anchor.offset));
                 const int move = right_move(ix, span.anchor);
                 if (STATS) ls.contig_reads++;
                 const bool in_loop = rest > move;
@@ -1155,7 +1147,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         state = N_AFTER;
                     } else if (SUCCESSORS) {
                         // the junction lookup (:309-311) from the record: Y_RJ's part of A_LOOKUP
-                        if (!SKM_SUCC_EARLY) next = load_successors<true>(ix, span.anchor, true);
                         span.anchor = junction_successor(next, span.anchor, read_code(rv, span.end + K - 1));
                         if (span.anchor.offset >= 0) state = M_RJ;
                         else { span.n = 0; state = N_AFTER; }                                    // :312-315
@@ -1518,6 +1509,13 @@ void launch_map_units(const DevIndex &ix, const MapBatch &b, int grid_blocks, in
         hipLaunchKernelGGL((map_units_kernel<false, true>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
     else
         hipLaunchKernelGGL((map_units_kernel<false, false>), dim3(grid_blocks), dim3(MAP_THREADS), 0, stream, ix, b);
+}
+
+void warm_code_map()
+{
+    hipFuncAttributes attributes;
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&map_units_kernel<false, true>));
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&unpack_reads_kernel));
 }
 
 }  // namespace skm

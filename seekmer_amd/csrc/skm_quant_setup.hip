@@ -43,9 +43,13 @@ struct Scratch {
         for (void *p : held) pool_free(p);
     }
 };
-#define QB_ALLOC(var, type, n) type *var = scratch.alloc<type>(n); if (!var) return -1
+// what failed last, for the caller's message (hipGetLastError is consumed by the check itself)
+thread_local char g_setup_failure[160] = "";
+#define QB_ALLOC(var, type, n) type *var = scratch.alloc<type>(n); \
+    if (!var) { snprintf(g_setup_failure, sizeof(g_setup_failure), "no memory for %s", #var); return -1; }
 
-#define QB_TRY(call) do { if ((call) != hipSuccess) return -1; } while (0)
+#define QB_TRY(call) do { const hipError_t qb_e = (call); if (qb_e != hipSuccess) { \
+    snprintf(g_setup_failure, sizeof(g_setup_failure), "%s: %s", #call, hipGetErrorString(qb_e)); return -1; } } while (0)
 
 __global__ void __launch_bounds__(256)
 iota_kernel(int32_t *out, int64_t n)
@@ -472,6 +476,15 @@ int64_t quant_setup(const ClassTable *table, QuantBuild &q, int32_t *perm, hipSt
         return n_rows;
     }
     return -1;
+}
+
+const char *quant_setup_failure() { return g_setup_failure; }
+
+void warm_code_quant_setup()
+{
+    hipFuncAttributes attributes;
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&iota_kernel));
+    (void)hipFuncGetAttributes(&attributes, reinterpret_cast<const void *>(&table_dump_kernel));
 }
 
 }  // namespace skm

@@ -271,8 +271,8 @@ def _quant_for(results, device=0):
     return _QuantHandle.from_csr(n_tx, offsets, targets, results.class_count, device), True
 
 
-def quantify(results, x0=None, bootstrap=False, seed=None, fixed_iters=0, return_iters=False):
-    """Estimate the transcript abundance (seekmer/infer.py:88-130)."""
+def quantify(results, x0=None, bootstrap=False, seed=None, fixed_iters=0, return_iters=False, device=0):
+    """Estimate the transcript abundance (seekmer/infer.py:88-130) on GPU `device`."""
     transcript_length = results.effective_lengths.astype('f8')
     if results.class_map.size == 0:
         zeros = numpy.zeros(results.effective_lengths.size).astype('f8')
@@ -282,7 +282,7 @@ def quantify(results, x0=None, bootstrap=False, seed=None, fixed_iters=0, return
     else:
         x = x0.copy()
     x /= x.sum()
-    quant, owned = _quant_for(results)
+    quant, owned = _quant_for(results, device)
     try:
         if bootstrap:
             if seed is None:
@@ -319,8 +319,8 @@ def quantify_resident(map_result, comm=None, return_iters=False, return_effectiv
     return out if len(out) > 1 else tpm
 
 
-def bootstrap_quantify(results, x0, n_boot, seed=None):
-    """The `-b N` loop of run() (seekmer/infer.py:79-82) as one device call."""
+def bootstrap_quantify(results, x0, n_boot, seed=None, device=0):
+    """The `-b N` loop of run() (seekmer/infer.py:79-82) as one device call on GPU `device`."""
     if n_boot <= 0:
         return []
     transcript_length = results.effective_lengths.astype('f8')
@@ -330,7 +330,7 @@ def bootstrap_quantify(results, x0, n_boot, seed=None):
         seed = int.from_bytes(__import__('os').urandom(8), 'little')
     x = x0.copy()
     x /= x.sum()
-    quant, owned = _quant_for(results)
+    quant, owned = _quant_for(results, device)
     try:
         out, _, _ = quant.bootstrap(n_boot, seed, x, transcript_length, tpm=True)
     finally:
@@ -372,7 +372,7 @@ def bootstrap_ranks(results, x0, n_boot, ranks, seed=None, device=0, share=_boot
     if n_boot <= 0:
         return []
     if ranks.world == 1:
-        return bootstrap_quantify(results, x0, n_boot, seed=seed)
+        return bootstrap_quantify(results, x0, n_boot, seed=seed, device=device)
     table = None
     if ranks.rank == 0:
         if seed is None:

@@ -158,6 +158,18 @@ class MapResult:
             int(unaligned),
             _native.ptr(numpy.ascontiguousarray(fld, dtype=numpy.int64), _native.c_i64p)))
 
+    def device_table(self):
+        """The table where it lies in HBM (skm_device_table): what a GPU-to-GPU hand-over copies."""
+        table = _native.DeviceTable()
+        _native.check(_native.hip().skm_mapper_device_table(self._handle, ctypes.byref(table)))
+        return table
+
+    def merge_resident(self, other):
+        """Counter.update + merge_fragment_lengths with a table that lies on the same GPU (another
+        MapResult, or a DeviceTable whose arrays were copied there): nothing crosses the host."""
+        table = other if isinstance(other, _native.DeviceTable) else other.device_table()
+        _native.check(_native.hip().skm_mapper_merge_device(self._handle, ctypes.byref(table)))
+
     def summarize(self):
         """seekmer/mapper.py:77-104: classes in Counter insertion order,
         class_map = int64[2, M] (row 0 class id, row 1 transcript id in tuple
@@ -312,6 +324,8 @@ class ReadMapper:
         reader = feeder.open()
         try:
             pieces = ctypes.c_int64()
+            # (the files' sizes say about how many units are coming: tables sized once, not grown)
+            _native.check(_native.hip().skm_mapper_expect_units(self.map_result._handle, reader.estimate()))
             _native.check(_native.hip().skm_mapper_map_packed_source(
                 self.map_result._handle, ctypes.cast(_native.host().skm_fastq_packed_next, ctypes.c_void_p),
                 reader.handle, int(feeder.paired), ctypes.byref(pieces)))

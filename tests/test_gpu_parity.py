@@ -437,7 +437,7 @@ def test_class_views_when_first_seen_values_are_shared(oracle, native_libs):
     np.testing.assert_allclose(x_own, x_dev, rtol=1e-6 if it_host != it_dev else 1e-9, atol=1e-300)
 
 
-def test_quantification_through_a_one_rank_communicator(oracle, native_libs):
+def test_quantification_through_a_one_rank_communicator(oracle, native_libs, monkeypatch):
     """The N > 1 data path with N = 1: an RCCL communicator of one rank is created as the ranks of
     a sharded run create theirs, skm_quant_infer all-reduces the histogram + aligned total and the
     per-step numerators through it, a bootstrap handle with the communicator attached takes the
@@ -472,6 +472,27 @@ def test_quantification_through_a_one_rank_communicator(oracle, native_libs):
         quant.close()
         np.testing.assert_array_equal(steps_c, steps)
         np.testing.assert_array_equal(through, plain)
+        # A rank whose shard produced NO class while the sample has aligned units elsewhere:
+        # it must still go through the set-up with empty class views and every collective of the EM.
+        # One rank cannot reach that state by itself, so a test hook adds "units the other ranks
+        # aligned" to the reduced total.  With nobody contributing numerators the first step leaves
+        # no abundance above the floor -- the defined outcome (numpy raises on max() of an empty
+        # selection, seekmer/infer.py:160) -- after the step's collectives have all run.
+        junk = np.random.default_rng(3).integers(0, 4, 2 * 5000 * 100).astype(np.uint8)
+        junk = np.frombuffer(bytes(junk).translate(bytes.maketrans(bytes(range(4)), b'ACGT')), dtype=np.uint8)
+        empty, _ = _run_gpu(index, np.concatenate([junk, np.zeros(1, np.uint8)]),
+                            np.arange(2 * 5000 + 1, dtype=np.int64) * 100, 5000, True)
+        assert empty.sizes()[0] == 0 and empty.sizes()[2] == 5000          # no class, everything unaligned
+        zeros, it0 = infer.quantify_resident(empty, comm=comm, return_iters=True)
+        assert it0 == 0 and not zeros.any()                                # alone: nothing to quantify
+        monkeypatch.setenv('SKM_TEST_ALIGNED_GLOBAL', '123456')
+        with pytest.raises(_native.NativeError) as raised:
+            infer.quantify_resident(empty, comm=comm, return_iters=True)
+        assert raised.value.code == _native.SKM_ERR_UNDEFINED
+        monkeypatch.delenv('SKM_TEST_ALIGNED_GLOBAL')
+        again, it_again = infer.quantify_resident(result, comm=comm, return_iters=True)    # the communicator is still in step
+        assert it_again == iters
+        np.testing.assert_array_equal(again, tpm)
     finally:
         parallel.destroy_comm(comm)
 
@@ -1482,3 +1503,52 @@ def test_pairs_of_files_of_unequal_length_and_a_pusher_at_the_byte_limit(oracle,
         rm.push_packed(piece)                 # (hung here before: 50 < PACKED_MIN_UNITS and nobody flushing)
     rm.push_packed(tail)
     _compare_tables(oracle, expected, fld, limited)
+
+
+def test_tables_merge_on_the_device(oracle, native_libs, chr21, chr21_oracle_index):
+    """SURVEY 8(e).1 without the host: a mapper's class table where it lies in HBM
+    (skm_mapper_device_table: registry order, counts as doubles, the arena) merged into another
+    mapper on the same GPU (skm_mapper_merge_device) -- what a hand-over between GPUs does after
+    copying those arrays over xGMI -- against the host-array merge (skm_mapper_merge over
+    skm_mapper_export), against one mapper that saw the whole sample, and against the oracle: the
+    same classes in the same first-seen order, counts, histogram and totals, bit for bit, whichever
+    of the three shares is the receiver."""
+    from seekmer_amd import common, mapper, parallel
+    rng = np.random.default_rng(41)
+    reads = _adversarial_reads(chr21[1], rng, 2 * 6000, 100)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = 6000
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, True, fld)
+    cuts = [0, 2500, 2501, n_units]
+
+    def shares():
+        out = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            share = mapper.MapResult(index)
+            sub = np.ascontiguousarray(offsets[2 * lo:2 * hi + 1])
+            mapper.ReadMapper(index, share).map_batch(common.ReadBatch(hi - lo, bases, sub, True, first_unit=lo))
+            out.append(share)
+        return out
+
+    by_host = shares()
+    parallel.merge_into(by_host[0], [parallel.rank_table(s) for s in by_host[1:]])
+    _compare_tables(oracle, expected, fld, by_host[0])
+    reference = by_host[0].export()
+    for receiver in range(3):
+        on_device = shares()
+        for k, other in enumerate(on_device):
+            if k != receiver:
+                on_device[receiver].merge_resident(other)
+        for got, want in zip(on_device[receiver].export(), reference):       # (first-seen values included)
+            np.testing.assert_array_equal(got, want)
+        assert on_device[receiver].sizes() == by_host[0].sizes()
+    # an empty table on either side
+    empty = mapper.MapResult(index)
+    empty.merge_resident(by_host[0])
+    for got, want in zip(empty.export(), reference):
+        np.testing.assert_array_equal(got, want)
+    by_host[0].merge_resident(mapper.MapResult(index))
+    for got, want in zip(by_host[0].export(), reference):
+        np.testing.assert_array_equal(got, want)
