@@ -375,9 +375,9 @@ def cold_child(args):
     from seekmer_amd import _native, common, infer, mapper
     index_path, r1, r2 = args.cold_child
     t_start = time.perf_counter()
+    _native.check(_native.hip().skm_pinned_set_device(0))      # (as infer.run: first thing, before the index is loaded)
     index = common.KMerIndex.load(index_path)
     index.device_handle(0)
-    _native.check(_native.hip().skm_pinned_set_device(0))
     result = mapper.MapResult(index)
     rm = mapper.ReadMapper(index, result)
     _native.check(_native.hip().skm_device_synchronize(0))        # (scripts/cold_timeline.py: start of the timed region)

@@ -75,9 +75,11 @@ int skm_device_gather_ceiling(int device, int64_t table_bytes, int blocks, int p
  * (seekmer/_common.pyx:21-48).  Host arrays are borrowed for the call and
  * copied to HBM (the pooled sequences are re-packed to 2 bits per base); the
  * handle owns device memory only.  Limits (SKM_ERR_ARG beyond them): n_slots a
- * power of two <= 2^31, n_contigs < 2^26, n_targets + 16 n_contigs < 2^30 (the
- * contig rows carry their first eight targets: one int32 address space),
- * n_bases < 2^31, at most 2^22 - 1 targets per contig. */
+ * power of two <= 2^31, n_contigs < 2^25, n_targets + 32 n_contigs < 2^30 (the
+ * contig records carry their first eight targets and their junction successors:
+ * one int32 address space), n_bases < 2^31, at most 2^22 - 1 targets per contig.
+ * skm_index_destroy gives up the caller's handle; the device copy is released once
+ * every mapper created from it has been destroyed too (in either order). */
 typedef struct skm_index skm_index;
 int skm_index_create(const void *kmers, int64_t n_slots,
                      const void *contigs, int64_t n_contigs,

@@ -50,6 +50,16 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
+// SKM_TRACE_STALE=1: report (and clear) a HIP error that some earlier call left behind (tuning aid)
+#define STALE_CHECK(where)                                                                           \
+    do {                                                                                             \
+        static const bool trace_stale_ = getenv("SKM_TRACE_STALE") != nullptr;                       \
+        if (trace_stale_) {                                                                          \
+            const hipError_t s_ = hipGetLastError();                                                 \
+            if (s_ != hipSuccess) fprintf(stderr, "[skm] stale HIP error at %s: %s\n", where, hipGetErrorString(s_)); \
+        }                                                                                            \
+    } while (0)
+
 #define SKM_TRY(call)          \
     do {                       \
         int rc_ = (call);      \
@@ -113,6 +123,10 @@ struct skm_index {
     int64_t n_slots = 0, bytes = 0;
     int64_t layout[8] = {0};          // skm_index_layout
     int cu_count = 256;
+    // the caller's handle + one per mapper that maps against it: skm_index_destroy only gives up the
+    // caller's, the device copy goes with the last one (garbage collectors finalise a mapper and
+    // its index in any order; a mapper destroyed after its index used to read freed memory here)
+    std::atomic<int> holders{1};
 };
 
 struct skm_mapper {
@@ -682,6 +696,7 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
 extern "C" int skm_index_destroy(skm_index *ix)
 {
     if (!ix) return SKM_OK;
+    if (ix->holders.fetch_sub(1) > 1) return SKM_OK;      // a mapper still maps against it
     (void)hipSetDevice(ix->device);
     (void)hipFree(ix->kmers); (void)hipFree(ix->contigs); (void)hipFree(ix->targets); (void)hipFree(ix->seq2);
     (void)hipFree(ix->buckets);
@@ -1019,6 +1034,7 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
     SKM_TRY(set_device(ix->device));
     skm_mapper *m = new skm_mapper();
     m->ix = ix;
+    ix->holders.fetch_add(1);
     HIP_TRY(pool_stream_acquire(&m->stream));
     for (auto &e : m->ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipHostMalloc((void **)&m->pinned, 64 * sizeof(unsigned long long)));
@@ -1030,7 +1046,7 @@ extern "C" int skm_mapper_create(skm_index *ix, skm_mapper **out)
                &m->vote[5], &m->vote[6]);
     HIP_TRY(hipStreamCreateWithFlags(&m->packed_stream, hipStreamNonBlocking));   // (10 ms: not at the first piece's push)
     int rc = table_reset(m, 1 << 16);
-    if (rc != SKM_OK) { delete m; return rc; }
+    if (rc != SKM_OK) { delete m; ix->holders.fetch_sub(1); return rc; }
     HIP_TRY(hipStreamSynchronize(m->stream));
     *out = m;
     return SKM_OK;
@@ -1064,8 +1080,9 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     for (auto &e : m->ev) (void)hipEventDestroy(e);
     if (m->pinned) (void)hipHostFree(m->pinned);
     pool_stream_release(m->stream);
+    skm_index *const ix = m->ix;
     delete m;
-    return SKM_OK;
+    return skm_index_destroy(ix);                          // (the mapper's hold on the index)
 }
 
 namespace {
@@ -1955,6 +1972,7 @@ namespace {
 
 int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64_t n_ids)
 {
+    STALE_CHECK("quant_alloc entry");
     q->device = device;
     q->n_tx = n_tx;
     q->n_classes = n_classes;
@@ -1983,6 +2001,7 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     SKM_TRY(q->ctl.ensure(16));
     SKM_TRY(q->part_max.ensure(EM_FINAL_BLOCKS));
     SKM_TRY(q->part_flags.ensure(EM_FINAL_BLOCKS));
+    STALE_CHECK("quant_alloc exit");
     return SKM_OK;
 }
 
@@ -2005,6 +2024,7 @@ QuantBuild quant_build_view(skm_quant *q)
 
 int quant_finish_setup(skm_quant *q, const ClassTable *table, int64_t units_seen = -1)
 {
+    STALE_CHECK("quant_finish_setup");
     QuantBuild b = quant_build_view(q);
     b.first_seen_bound = units_seen > 0 ? units_seen : 0;      // first-seen values are unit indices below this
     const int64_t rows = quant_setup(table, b, q->perm.p, q->stream);
@@ -2356,6 +2376,7 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
 extern "C" int skm_quant_destroy(skm_quant *q)
 {
     if (!q) return SKM_OK;
+    STALE_CHECK("quant_destroy entry");
     (void)hipSetDevice(q->device);
     (void)hipStreamSynchronize(q->stream);
     q->cls_offset.release(); q->row_start.release(); q->tx_row.release(); q->ids.release();
@@ -2371,6 +2392,7 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     pool_pinned_release(q->pinned);
     pool_stream_release(q->stream);
     delete q;
+    STALE_CHECK("quant_destroy exit");
     return SKM_OK;
 }
 
@@ -2549,6 +2571,8 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     p.n_total = (double)n_draws; p.rel_tol = rel_tol; p.x_floor = x_floor;
     p.ctl = w.ctl.p; p.part_max = w.part_max.p; p.part_flags = w.part_flags.p;
     p.managed = 1;
+    p.mgr = w.mgr.p;
+    p.iters_out = w.iters.p;
     int64_t chunk = 16;                                          // steps queued between two looks at the progress
     if (const char *e = getenv("SKM_BOOTSTRAP_CHUNK")) chunk = std::max<int64_t>(1, atoll(e));   // (tests)
     unsigned long long *const look = q->pinned + 64;             // 64 + 8 words of the pinned block
@@ -2563,14 +2587,14 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
         HIP_TRY(hipGetLastError());
         for (int64_t k = 0;;) {
             for (int64_t i = 0; i < chunk; ++i, ++k) {
-                launch_em_batch_step(p, k, q->stream);
-                launch_em_batch_manage(p, w.mgr.p, w.counts_all.p, q->x_start.p, q->boot_out.p, w.iters.p, k, q->stream);
+                launch_em_batch_step(p, k, q->stream);        // (its first kernel also plans for what has stopped)
+                launch_em_batch_manage(p, w.mgr.p, w.counts_all.p, q->x_start.p, q->boot_out.p, w.iters.p, k, true, q->stream);
             }
             // before the host looks, the last pass is judged too (otherwise only the next step's first
             // kernel would) and what it stops is taken: a place that is still occupied then is running
             launch_em_batch_decide(p, k, q->stream);
-            launch_em_batch_manage(p, w.mgr.p, w.counts_all.p, q->x_start.p, q->boot_out.p, w.iters.p, k - 1, q->stream);
-            q->launches += 5 * chunk + 3;
+            launch_em_batch_manage(p, w.mgr.p, w.counts_all.p, q->x_start.p, q->boot_out.p, w.iters.p, k - 1, false, q->stream);
+            q->launches += 4 * chunk + 3;
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(look, w.mgr.p, 24 * 8, hipMemcpyDeviceToHost, q->stream));
             HIP_TRY(hipMemcpyAsync(look + 24, w.ctl.p, 8 * 8, hipMemcpyDeviceToHost, q->stream));

@@ -78,6 +78,51 @@ __device__ unsigned int evaluate_batch(const EmBatchProblem &p, int n_parts, int
     return mask;
 }
 
+// mgr words: see "the working set kept full by the device" below
+enum { MGR_NEXT = 0, MGR_COUNT = 1, MGR_FINISHED = 2, MGR_UNDEFINED = 3, MGR_REP = 8, MGR_SINCE = 16, MGR_TAKE = 24,
+       MGR_PUT = 32 };
+
+// What a latched stop means, place by place (one lane): the replicate's step count is recorded, its
+// result is to be taken, the next replicate of the group (if any) is to be put in its place; the plan
+// goes to mgr[MGR_TAKE ..], mgr[MGR_PUT ..] for em_batch_refill.  `deferred`: called from inside a step
+// (block 0 of em_inner_batch, right after it has judged the step before), where the control block
+// must stay as the step's other kernels read it -- a stopped place has to be carried through the
+// step's finalize pass -- so the control words of a refilled place and the "all done" latch are
+// left to em_batch_refill, which runs behind the step.
+__device__ void plan_places(const EmBatchProblem &p, unsigned long long *mgr, int64_t *iters_out, int64_t step, bool deferred)
+{
+    bool any = false;
+    for (int r = 0; r < R; ++r) {
+        unsigned long long take = 0, put = 0;
+        if (mgr[MGR_REP + r] != 0 && p.ctl[BCTL_DONE + r]) {
+            const unsigned long long rep = mgr[MGR_REP + r] - 1;
+            if (iters_out) iters_out[rep] = (int64_t)(p.ctl[BCTL_ITERS + r] - mgr[MGR_SINCE + r]);
+            if (p.ctl[BCTL_UNDEFINED + r]) mgr[MGR_UNDEFINED] = 1;
+            take = rep + 1;
+            mgr[MGR_FINISHED] += 1;
+            if (mgr[MGR_NEXT] < mgr[MGR_COUNT]) {
+                put = ++mgr[MGR_NEXT];                              // (replicate mgr[MGR_NEXT] - 1, + 1)
+                mgr[MGR_REP + r] = put;
+                mgr[MGR_SINCE + r] = (unsigned long long)(step + 1);
+                if (!deferred) {
+                    p.ctl[BCTL_DONE + r] = 0;
+                    p.ctl[BCTL_UNDEFINED + r] = 0;
+                    p.ctl[BCTL_ITERS + r] = 0;
+                }
+            } else {
+                mgr[MGR_REP + r] = 0;                               // idle from now on (it stays "stopped")
+            }
+        }
+        mgr[MGR_TAKE + r] = take;
+        mgr[MGR_PUT + r] = put;
+        any |= mgr[MGR_REP + r] != 0;
+    }
+    if (!any && !deferred) {
+        p.ctl[BCTL_LAST_STEP] = (unsigned long long)(step + 1);
+        p.ctl[BCTL_ALL_DONE] = 1;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 em_inner_batch_kernel(EmBatchProblem p, int parity, int eval_parts, int64_t steps_done)
 {
@@ -89,6 +134,9 @@ em_inner_batch_kernel(EmBatchProblem p, int parity, int eval_parts, int64_t step
     // wait (see em_inner_kernel: a pass of `inner` nobody reads, once per batch)
     if (eval_parts > 0 && blockIdx.x == 0
             && evaluate_batch(p, eval_parts, steps_done, true) == (1u << R) - 1u && !p.managed) return;
+    // the device-managed working set: what has just been latched is planned for at once (the launch
+    // of its own that used to do this after every step is gone); em_batch_refill carries it out
+    if (p.managed && p.mgr && blockIdx.x == 0 && threadIdx.x == 0) plan_places(p, p.mgr, p.iters_out, steps_done, true);
     // R lanes per class, lane r = replicate r: the R lanes of a class read one 64-byte sector of x per
     // id together and four ids are in flight per lane (one lane per class with the replicates in
     // registers had ONE dependent 64-byte gather in flight per lane: 86 us per step against 50 for the
@@ -225,51 +273,32 @@ em_batch_take_kernel(const double *__restrict__ x, int64_t n_tx, int r, double *
 // [1] replicates in the group, [2] finished, [3] a replicate had no abundance above x_floor,
 // [8 + r] replicate in place r + 1 (0: idle), [16 + r] the step it started at, [24 + r] / [32 + r]
 // the plan of this step: replicate to take / to put, + 1.
-enum { MGR_NEXT = 0, MGR_COUNT = 1, MGR_FINISHED = 2, MGR_UNDEFINED = 3, MGR_REP = 8, MGR_SINCE = 16, MGR_TAKE = 24,
-       MGR_PUT = 32 };
-
 __global__ void em_batch_assign_kernel(EmBatchProblem p, unsigned long long *mgr, int64_t *iters_out, int64_t step)
 {
     if (threadIdx.x != 0 || p.ctl[BCTL_ALL_DONE]) return;
-    bool any = false;
-    for (int r = 0; r < R; ++r) {
-        unsigned long long take = 0, put = 0;
-        if (mgr[MGR_REP + r] != 0 && p.ctl[BCTL_DONE + r]) {
-            const unsigned long long rep = mgr[MGR_REP + r] - 1;
-            if (iters_out) iters_out[rep] = (int64_t)(p.ctl[BCTL_ITERS + r] - mgr[MGR_SINCE + r]);
-            if (p.ctl[BCTL_UNDEFINED + r]) mgr[MGR_UNDEFINED] = 1;
-            take = rep + 1;
-            mgr[MGR_FINISHED] += 1;
-            if (mgr[MGR_NEXT] < mgr[MGR_COUNT]) {
-                put = ++mgr[MGR_NEXT];                              // (replicate mgr[MGR_NEXT] - 1, + 1)
-                mgr[MGR_REP + r] = put;
-                mgr[MGR_SINCE + r] = (unsigned long long)(step + 1);
-                p.ctl[BCTL_DONE + r] = 0;
-                p.ctl[BCTL_UNDEFINED + r] = 0;
-                p.ctl[BCTL_ITERS + r] = 0;
-            } else {
-                mgr[MGR_REP + r] = 0;                               // idle from now on (it stays "stopped")
-            }
-        }
-        mgr[MGR_TAKE + r] = take;
-        mgr[MGR_PUT + r] = put;
-        any |= mgr[MGR_REP + r] != 0;
-    }
-    if (!any) {
-        p.ctl[BCTL_LAST_STEP] = (unsigned long long)(step + 1);
-        p.ctl[BCTL_ALL_DONE] = 1;
-    }
+    plan_places(p, mgr, iters_out, step, false);
 }
 
 // the plan carried out; `into` = the abundance buffer the NEXT step reads (a stopped replicate's
 // result is carried there by the finalize pass of this step)
 __global__ void __launch_bounds__(256)
 em_batch_refill_kernel(EmBatchProblem p, const unsigned long long *__restrict__ mgr, const double *__restrict__ counts_all,
-                       const double *__restrict__ x_start, double *__restrict__ out_all, double *__restrict__ into)
+                       const double *__restrict__ x_start, double *__restrict__ out_all, double *__restrict__ into,
+                       int64_t step)
 {
     __shared__ unsigned long long plan[2 * R];
     if (threadIdx.x < 2 * R) plan[threadIdx.x] = mgr[MGR_TAKE + threadIdx.x];     // (TAKE and PUT are adjacent)
     __syncthreads();
+    if (step >= 0 && blockIdx.x == 0 && threadIdx.x == 0 && !p.ctl[BCTL_ALL_DONE]) {
+        // what plan_places left for behind the step: a refilled place starts over, and when no place
+        // holds a replicate any more everything has finished
+        bool live = false;
+        for (int r = 0; r < R; ++r) {
+            if (plan[R + r]) { p.ctl[BCTL_DONE + r] = 0; p.ctl[BCTL_UNDEFINED + r] = 0; p.ctl[BCTL_ITERS + r] = 0; }
+            live |= mgr[MGR_REP + r] != 0;
+        }
+        if (!live) { p.ctl[BCTL_LAST_STEP] = (unsigned long long)(step + 1); p.ctl[BCTL_ALL_DONE] = 1; }
+    }
     bool any = false;
 #pragma unroll
     for (int i = 0; i < 2 * R; ++i) any |= plan[i] != 0;
@@ -340,15 +369,18 @@ void launch_em_batch_manage_init(const EmBatchProblem &p, unsigned long long *mg
     }
     (void)hipMemcpyAsync(mgr, host, 64 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream);
     hipLaunchKernelGGL(em_batch_ctl_kernel, dim3(1), dim3(64), 0, stream, p.ctl, idle);
-    hipLaunchKernelGGL(em_batch_refill_kernel, dim3(1024), dim3(256), 0, stream, p, mgr, counts_all, x_start, out_all, p.x[0]);
+    hipLaunchKernelGGL(em_batch_refill_kernel, dim3(1024), dim3(256), 0, stream, p, mgr, counts_all, x_start, out_all, p.x[0],
+                       (int64_t)-1);
 }
 
+// behind a step whose em_inner_batch has planned (p.mgr set): the refill alone; `planned` false (a
+// look between chunks, behind em_batch_decide): the plan first, as a launch of its own
 void launch_em_batch_manage(const EmBatchProblem &p, unsigned long long *mgr, const double *counts_all, const double *x_start,
-                            double *out_all, int64_t *iters_out, int64_t step, hipStream_t stream)
+                            double *out_all, int64_t *iters_out, int64_t step, bool planned, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_batch_assign_kernel, dim3(1), dim3(64), 0, stream, p, mgr, iters_out, step);
+    if (!planned) hipLaunchKernelGGL(em_batch_assign_kernel, dim3(1), dim3(64), 0, stream, p, mgr, iters_out, step);
     hipLaunchKernelGGL(em_batch_refill_kernel, dim3(1024), dim3(256), 0, stream, p, mgr, counts_all, x_start, out_all,
-                       p.x[(step + 1) & 1]);
+                       p.x[(step + 1) & 1], step);
 }
 
 void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream)

@@ -194,6 +194,8 @@ struct EmBatchProblem {
     double *part_max;             // [EM_FINAL_BLOCKS][EM_BATCH]
     unsigned int *part_flags;     // [EM_FINAL_BLOCKS][EM_BATCH]
     int managed;                  // the device refills the places (launch_em_batch_manage): see skm_em_batch.hip
+    unsigned long long *mgr;      // managed: the manager's words, planned for inside em_inner_batch (or nullptr)
+    int64_t *iters_out;           // managed: step count of every replicate of the group
 };
 // The working set kept full by the device: `mgr` is 64 words of HBM; counts_all[i][C] the pre-drawn
 // class counts of replicate i of the group, out_all[i][T] its result, iters_out[i] its step count
@@ -204,7 +206,7 @@ void launch_em_batch_manage_init(const EmBatchProblem &p, unsigned long long *mg
                                  int64_t n_reps, const double *counts_all, const double *x_start, double *out_all,
                                  hipStream_t stream);
 void launch_em_batch_manage(const EmBatchProblem &p, unsigned long long *mgr, const double *counts_all, const double *x_start,
-                            double *out_all, int64_t *iters_out, int64_t step, hipStream_t stream);
+                            double *out_all, int64_t *iters_out, int64_t step, bool planned, hipStream_t stream);
 // one step (inner, rows, finalize); step > 0 first judges the step before it
 void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t stream);
 void launch_em_batch_decide(const EmBatchProblem &p, int64_t steps_done, hipStream_t stream);

@@ -62,9 +62,12 @@ def _run(ranks, start_time, index_path, output_path, fastq_paths, job_count, sav
     ranks.barrier()
     readmap = (output_path / 'readmap.txt').open('wt') if save_readmap else None
     _LOG.info('Inferring transcript abundance')
+    # (the readers' threads page-lock against THIS GPU; their arena is page-locked by a helper thread
+    # from here on, under the index load and upload)
+    _native.check(_native.hip().skm_pinned_set_device(device))
     index = common.KMerIndex.load(index_path)
+    index.device_handle(device)
     _LOG.info('Mapping all reads')
-    _native.check(_native.hip().skm_pinned_set_device(device))     # (the readers' threads page-lock against THIS GPU)
     read_feeder = _feeder(fastq_paths, not single_ended, parse_threads, ranks.shard, save_readmap)
     map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
                                   readmap=readmap, debug=debug, device=device)

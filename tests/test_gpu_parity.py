@@ -1528,7 +1528,8 @@ def test_tables_merge_on_the_device(oracle, native_libs, chr21, chr21_oracle_ind
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             share = mapper.MapResult(index)
             sub = np.ascontiguousarray(offsets[2 * lo:2 * hi + 1])
-            mapper.ReadMapper(index, share).map_batch(common.ReadBatch(hi - lo, bases, sub, True, first_unit=lo))
+            mapper.ReadMapper(index, share).map_batch_async(common.ReadBatch(hi - lo, bases, sub, True, first_unit=lo))
+            share.sync()                  # (first-seen values are global unit numbers: first_unit)
             out.append(share)
         return out
 
