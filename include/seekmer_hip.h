@@ -185,7 +185,9 @@ typedef struct skm_packed_reads {
  * pieces were cut or when they arrived: first-seen values are unit numbers. */
 int skm_mapper_push_packed(skm_mapper *mapper, const skm_packed_reads *piece, int paired);
 /* Drain a source of pieces (skm_fastq_packed_next with its reader as context) into the mapper
- * without leaving native code: next() until a piece with n_reads == 0 that is not a cut, every piece pushed.
+ * without leaving native code: next() until a piece with n_reads == 0 that is not a cut, every piece
+ * pushed.  A source must keep the arrays of a piece valid until it has been asked for the next
+ * piece BUT ONE: the copy of a piece to the GPU runs while the next piece is being fetched.
  * *n_pieces (optional) = pieces pushed. */
 typedef int (*skm_packed_source)(void *context, skm_packed_reads *piece);
 int skm_mapper_map_packed_source(skm_mapper *mapper, skm_packed_source next, void *context,
@@ -411,8 +413,10 @@ int skm_fastq_packed_open(const char *const *paths, int n_paths, int paired, int
 /* where the arrays that cross PCIe live (before the first _next; see skm_fastq_set_allocator) */
 int skm_fastq_packed_set_allocator(skm_fastq_packed *reader, void *(*alloc)(size_t),
                                    void (*release)(void *));
-/* next piece; piece->n_reads == 0 at the end.  The arrays stay valid until the next call.  The
- * signature is skm_packed_source (below) with the reader as context. */
+/* next piece; piece->n_reads == 0 (and code_words != SKM_PACKED_CUT) at the end.  The arrays stay
+ * valid through ONE more call (skm_packed_source's contract: the mapper's drain copies piece k to
+ * the GPU while it asks for piece k + 1).  The signature is skm_packed_source (below) with the
+ * reader as context. */
 int skm_fastq_packed_next(void *reader, skm_packed_reads *piece);
 /* stats[0]=pieces accepted as guessed [1]=pieces parsed again [2]=reads [3]=exceptions
  * [4]=parser variant in use (0 single characters, 1 16-byte blocks, 2 32-byte blocks)

@@ -152,6 +152,11 @@ struct skm_mapper {
     DBuf<unsigned long long> rec_tuple;
     unsigned long long *pinned = nullptr;   // host-pinned readback words
     DBuf<uint64_t> rec_key;
+    // the batch's records binned by table range (skm_classes.hip: counting by slot range)
+    DBuf<unsigned int> bin_words;
+    DBuf<int32_t> bin_unit, bin_ids;
+    DBuf<uint64_t> bin_key;
+    DBuf<unsigned long long> bin_tuple;
     bool keep_spans = false, last_spans = false;   // spans wanted / written by the last batch
     DBuf<int32_t> unit_entries;
     DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
@@ -502,6 +507,9 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                 pool_stream_release(a);
                 pool_stream_release(b);
             }
+            void *block[2] = {nullptr, nullptr};           // (and the control-block readbacks of two handles)
+            for (auto &p : block) if (pool_pinned_acquire(&p) != hipSuccess) p = nullptr;
+            for (auto &p : block) pool_pinned_release(p);
         });
     });
     auto join_warm = on_exit([&]() { warm.join(); });
@@ -950,18 +958,40 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(table_reserve(m, n_units));
     SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)ids + 1024), true, m->stream));
     bind_table(m, m->t.slot_mask + 1);
-    // A large batch on an empty table goes in two waves of records: once the classes of the first
+    // A large batch is counted by slot range: its records binned by the table range their key hashes
+    // to, one block per bin counting in LDS (skm_classes.hip).  The bins follow the table's size, so
+    // the table is sized first (table_reserve above) and a retry after a growth -- deferred records: a
+    // probe ran past its limit -- takes the plain kernel over the binned records, as small batches do
+    // over the batch's own.
+    const bool binned = class_binning_applies(m->t, n_units) && !getenv("SKM_NO_CLASS_BINS");
+    MapBatch cb = b;                          // the records the class kernels walk
+    BinPlan plan{};
+    if (binned) {
+        SKM_TRY(m->bin_words.ensure(CLASS_BIN_WORDS));
+        SKM_TRY(m->bin_unit.ensure(n_units)); SKM_TRY(m->bin_key.ensure(n_units)); SKM_TRY(m->bin_tuple.ensure(n_units));
+        SKM_TRY(m->bin_ids.ensure((size_t)ids + 1024));
+        plan = launch_class_bin(m->t, b, m->bin_words.p, m->bin_unit.p, m->bin_key.p, m->bin_tuple.p, m->bin_ids.p, m->stream);
+        cb.rec_unit = m->bin_unit.p; cb.rec_key = m->bin_key.p; cb.rec_tuple = m->bin_tuple.p;
+        cb.unit_entries = m->bin_ids.p;
+        HIP_TRY(hipMemsetAsync(m->unit_slot.p, 0xff, (size_t)n_units * sizeof(int64_t), m->stream));   // (-1: places no bin uses)
+    }
+    // Otherwise a large batch on an empty table goes in two waves of records: once the classes of the first
     // quarter are committed, most records of the rest land on a committed class and are verified
     // inside class_insert (the slot's tuple word came with the probe); class_verify's second random
     // pass over the table is left with the first wave and the records of classes new in the second.
-    const bool two_waves = m->host_classes == 0 && n_units >= (1 << 21);
+    const bool two_waves = !binned && m->host_classes == 0 && n_units >= (1 << 21);
     for (int pass = 0;; ++pass) {
         // insert (with the commit of the new classes) -> totals -> verify: one pipeline, one
         // synchronisation; the optimistic case needs a single pass
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
+        if (binned && pass == 0) {
+            launch_class_bin_insert(m->t, cb, plan, unit_base, m->unit_slot.p, true, m->stream);
+            launch_class_verify(m->t, cb, m->unit_slot.p, m->stream);
+        }
         // (wave borders in sixteenths of the batch; SKM_CLASS_WAVES="2,8" etc. is a tuning aid)
         int cuts[8] = {4, 16, 16, 16, 16, 16, 16, 16};
         int n_waves = two_waves && pass == 0 ? 2 : 1;
+        if (binned && pass == 0) n_waves = 0;
 #ifdef SKM_TUNING                                    // (tuning builds only: scripts/build_variant.sh)
         if (n_waves > 1)
             if (const char *e = getenv("SKM_CLASS_WAVES")) {
@@ -984,7 +1014,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         for (int wave = 0; wave < n_waves; ++wave) {
             const int64_t w0 = n_waves == 1 || wave == 0 ? 0 : n_units * cuts[wave - 1] / 16;
             const int64_t w1 = n_waves == 1 ? n_units : n_units * cuts[wave] / 16;
-            MapBatch part = b;                   // records [w0, w1) of the batch
+            MapBatch part = cb;                  // records [w0, w1) of the batch
             part.rec_unit += w0; part.rec_key += w0; part.rec_tuple += w0;
             part.n_units = w1 - w0;
             launch_class_insert(m->t, part, unit_base, m->unit_slot.p + w0, pass > 0, pass == 0 && wave == 0, m->stream);
@@ -1077,6 +1107,7 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
     m->rec_unit.release(); m->unit_anchor.release(); m->rec_tuple.release();
     m->unit_slot.release(); m->rec_key.release(); m->unit_entries.release(); m->batch_ctl.release();
+    m->bin_words.release(); m->bin_unit.release(); m->bin_ids.release(); m->bin_key.release(); m->bin_tuple.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
     if (m->pinned) (void)hipHostFree(m->pinned);
     pool_stream_release(m->stream);
@@ -1447,9 +1478,32 @@ extern "C" int skm_mapper_sync(skm_mapper *m)
     return wait_jobs(m, 0, true);
 }
 
+namespace {
+
+// A piece on its way into the mapper: `stage` checks it, waits at the byte limit, takes a block of HBM
+// and QUEUES the copies on the mapper's copy stream (*staged = false: a cut or an empty piece, dealt
+// with on the spot); `commit` -- once the copies have completed -- makes the piece visible to the worker.
+int packed_stage(skm_mapper *m, const skm_packed_reads *piece, int paired, skm_mapper::Piece *out, bool *staged);
+int packed_commit(skm_mapper *m, skm_mapper::Piece &&held, int stream_index);
+
+}  // namespace
+
 extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *piece, int paired)
 {
     if (!m || !piece) return fail(SKM_ERR_ARG, "NULL argument");
+    skm_mapper::Piece held;
+    bool staged = false;
+    SKM_TRY(packed_stage(m, piece, paired, &held, &staged));
+    if (!staged) return SKM_OK;
+    HIP_TRY(hipStreamSynchronize(m->packed_stream));        // (the caller's arrays are free again)
+    return packed_commit(m, std::move(held), piece->stream);
+}
+
+namespace {
+
+int packed_stage(skm_mapper *m, const skm_packed_reads *piece, int paired, skm_mapper::Piece *out, bool *staged)
+{
+    *staged = false;
     const int64_t n = piece->n_reads;
     const int cw = piece->code_words;
     if (n < 0 || n >= (1LL << 31) || piece->first_read < 0) return fail(SKM_ERR_ARG, "bad piece: %lld reads from %lld", (long long)n, (long long)piece->first_read);
@@ -1515,7 +1569,7 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
     }
     char *raw = nullptr;
     HIP_TRY(pool_alloc((void **)&raw, (size_t)block_bytes));
-    skm_mapper::Piece held;
+    skm_mapper::Piece &held = *out;
     {
         std::shared_ptr<std::atomic<int64_t>> counter = m->packed_bytes;   // (outlives the mapper if a block does)
         counter->fetch_add(block_bytes);
@@ -1541,14 +1595,19 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
         HIP_TRY(hipMemcpyAsync(held.exc_reads_dev, piece->exception_reads, (size_t)n_exc * 4, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(held.exc_masks, piece->exception_masks, (size_t)n_exc * cw * 4, hipMemcpyHostToDevice, stream));
     }
-    HIP_TRY(hipStreamSynchronize(stream));        // (the caller's arrays are free again)
+    *staged = true;
+    return SKM_OK;
+}
+
+int packed_commit(skm_mapper *m, skm_mapper::Piece &&held, int stream_index)
+{
     {
         std::unique_lock<std::mutex> hold(m->q_mu);
         if (!m->worker_started) {
             m->worker = std::thread(worker_main, m);
             m->worker_started = true;
         }
-        auto &list = m->pending[piece->stream];
+        auto &list = m->pending[stream_index];
         // a piece that overlaps what its stream holds replaces the reads from its first one on
         auto overlapping = [&] {
             for (const auto &other : list)
@@ -1586,18 +1645,48 @@ extern "C" int skm_mapper_push_packed(skm_mapper *m, const skm_packed_reads *pie
     return SKM_OK;
 }
 
+}  // namespace
+
 extern "C" int skm_mapper_map_packed_source(skm_mapper *m, skm_packed_source next, void *context, int paired,
                                             int64_t *n_pieces)
 {
     if (!m || !next) return fail(SKM_ERR_ARG, "NULL argument");
     if (n_pieces) *n_pieces = 0;
+    // The copy of piece k runs while the source is asked for piece k + 1 (a source keeps a piece's
+    // arrays valid through ONE more call, include/seekmer_hip.h): the drain loop -- one thread --
+    // paid every piece's copy time in full before (524 pieces x 25 us of a 42 ms pass).
+    SKM_TRY(set_device(m->ix->device));
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    auto undo = on_exit([&]() { for (auto &e : copied) pool_event_release(e, false); });
+    for (auto &e : copied) HIP_TRY(pool_event_acquire(&e, false));
+    skm_mapper::Piece waiting;
+    bool have_waiting = false;
+    int waiting_stream = 0, turn = 0;
+    auto land = [&]() -> int {                   // the piece whose copy was queued a call ago joins its stream
+        if (!have_waiting) return SKM_OK;
+        have_waiting = false;
+        HIP_TRY(hipEventSynchronize(copied[turn ^ 1]));
+        return packed_commit(m, std::move(waiting), waiting_stream);
+    };
     for (;;) {
         skm_packed_reads piece;
         memset(&piece, 0, sizeof(piece));
         const int rc = next(context, &piece);
-        if (rc != SKM_OK) return fail(rc, "the source of packed reads failed (%d)", rc);
-        if (piece.n_reads == 0 && piece.code_words != SKM_PACKED_CUT) return SKM_OK;
-        SKM_TRY(skm_mapper_push_packed(m, &piece, paired));
+        if (rc != SKM_OK) { (void)land(); return fail(rc, "the source of packed reads failed (%d)", rc); }
+        if (piece.n_reads == 0 && piece.code_words != SKM_PACKED_CUT) return land();
+        if (piece.n_reads == 0) SKM_TRY(land());         // a cut applies behind everything that came before it
+        skm_mapper::Piece held;
+        bool staged = false;
+        const int staged_rc = packed_stage(m, &piece, paired, &held, &staged);
+        if (staged_rc != SKM_OK) { (void)land(); return staged_rc; }
+        if (staged) HIP_TRY(hipEventRecord(copied[turn], m->packed_stream));
+        SKM_TRY(land());
+        if (staged) {
+            waiting = std::move(held);
+            waiting_stream = piece.stream;
+            have_waiting = true;
+            turn ^= 1;
+        }
         if (n_pieces) ++*n_pieces;
     }
 }

@@ -169,10 +169,14 @@ size_t g_map_keep_bytes = 0;
 
 void unmap_in_pieces(const char *p, size_t n)
 {
-    constexpr size_t PIECE = 32u << 20;            // the memory-map lock is released between pieces
+    // The memory-map lock is released between pieces -- and left alone for a moment: a thread that
+    // needs it (hipHostMalloc, hipMalloc, hipStreamCreate of the quantification that follows a mapping
+    // run) got it only after the whole teardown when the pieces were 32 MB with a yield in between
+    // (measured: the first such call of the next phase took 115-137 ms behind 4.4 GB of text).
+    constexpr size_t PIECE = 4u << 20;
     for (size_t at = 0; at < n; at += PIECE) {
         munmap((void *)(p + at), std::min(PIECE, n - at));
-        std::this_thread::yield();
+        std::this_thread::sleep_for(std::chrono::microseconds(40));
     }
 }
 

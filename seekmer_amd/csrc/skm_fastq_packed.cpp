@@ -161,7 +161,7 @@ struct skm_fastq_packed {
     std::vector<int64_t> file_reads;
     int64_t stream_next[2] = {0, 0};
     int64_t pair_base = 0;
-    PackedOut *cur = nullptr;
+    PackedOut *cur = nullptr, *prev = nullptr;      // the piece handed out last, and the one before it
     int64_t accepted = 0, reparsed = 0, n_reads = 0, n_exceptions = 0;
     bool failed = false;
     const bool trace = getenv("SKM_FASTQ_TRACE") != nullptr;      // tuning aid: per-piece timings on stderr
@@ -223,6 +223,7 @@ struct skm_fastq_packed {
         for (auto &t : workers) t.join();
         for (auto &kv : ready) give_piece(kv.second.out);
         give_piece(cur);
+        give_piece(prev);
         for (auto &f : files) f.unmap();
     }
 };
@@ -297,7 +298,10 @@ extern "C" int skm_fastq_packed_next(void *reader, skm_packed_reads *piece)
         q->started = true;
         for (int t = 0; t < q->n_threads; ++t) q->workers.emplace_back([q]() { q->worker_main(); });
     }
-    give_piece(q->cur);
+    // a piece's arrays stay valid through ONE more call: whoever copies them asynchronously (the
+    // mapper's drain) asks for the next piece while that copy runs
+    give_piece(q->prev);
+    q->prev = q->cur;
     q->cur = nullptr;
     for (;;) {
         if (q->next_deliver >= q->items.size()) return SKM_OK;       // n_reads == 0: the end
