@@ -152,11 +152,6 @@ struct skm_mapper {
     DBuf<unsigned long long> rec_tuple;
     unsigned long long *pinned = nullptr;   // host-pinned readback words
     DBuf<uint64_t> rec_key;
-    // the batch's records binned by table range (skm_classes.hip: counting by slot range)
-    DBuf<unsigned int> bin_words;
-    DBuf<int32_t> bin_unit, bin_ids;
-    DBuf<uint64_t> bin_key;
-    DBuf<unsigned long long> bin_tuple;
     bool keep_spans = false, last_spans = false;   // spans wanted / written by the last batch
     DBuf<int32_t> unit_entries;
     DBuf<unsigned long long> batch_ctl;  // [0]=ids_cursor [8..2007]=fld [2048..2063]=stats
@@ -958,40 +953,18 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
     SKM_TRY(table_reserve(m, n_units));
     SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)ids + 1024), true, m->stream));
     bind_table(m, m->t.slot_mask + 1);
-    // A large batch is counted by slot range: its records binned by the table range their key hashes
-    // to, one block per bin counting in LDS (skm_classes.hip).  The bins follow the table's size, so
-    // the table is sized first (table_reserve above) and a retry after a growth -- deferred records: a
-    // probe ran past its limit -- takes the plain kernel over the binned records, as small batches do
-    // over the batch's own.
-    const bool binned = class_binning_applies(m->t, n_units) && !getenv("SKM_NO_CLASS_BINS");
-    MapBatch cb = b;                          // the records the class kernels walk
-    BinPlan plan{};
-    if (binned) {
-        SKM_TRY(m->bin_words.ensure(CLASS_BIN_WORDS));
-        SKM_TRY(m->bin_unit.ensure(n_units)); SKM_TRY(m->bin_key.ensure(n_units)); SKM_TRY(m->bin_tuple.ensure(n_units));
-        SKM_TRY(m->bin_ids.ensure((size_t)ids + 1024));
-        plan = launch_class_bin(m->t, b, m->bin_words.p, m->bin_unit.p, m->bin_key.p, m->bin_tuple.p, m->bin_ids.p, m->stream);
-        cb.rec_unit = m->bin_unit.p; cb.rec_key = m->bin_key.p; cb.rec_tuple = m->bin_tuple.p;
-        cb.unit_entries = m->bin_ids.p;
-        HIP_TRY(hipMemsetAsync(m->unit_slot.p, 0xff, (size_t)n_units * sizeof(int64_t), m->stream));   // (-1: places no bin uses)
-    }
-    // Otherwise a large batch on an empty table goes in two waves of records: once the classes of the first
+    // A large batch on an empty table goes in two waves of records: once the classes of the first
     // quarter are committed, most records of the rest land on a committed class and are verified
     // inside class_insert (the slot's tuple word came with the probe); class_verify's second random
     // pass over the table is left with the first wave and the records of classes new in the second.
-    const bool two_waves = !binned && m->host_classes == 0 && n_units >= (1 << 21);
+    const bool two_waves = m->host_classes == 0 && n_units >= (1 << 21);
     for (int pass = 0;; ++pass) {
         // insert (with the commit of the new classes) -> totals -> verify: one pipeline, one
         // synchronisation; the optimistic case needs a single pass
         HIP_TRY(hipMemsetAsync(m->counters.p + CTR_DEFERRED, 0, 8, m->stream));
-        if (binned && pass == 0) {
-            launch_class_bin_insert(m->t, cb, plan, unit_base, m->unit_slot.p, true, m->stream);
-            launch_class_verify(m->t, cb, m->unit_slot.p, m->stream);
-        }
         // (wave borders in sixteenths of the batch; SKM_CLASS_WAVES="2,8" etc. is a tuning aid)
         int cuts[8] = {4, 16, 16, 16, 16, 16, 16, 16};
         int n_waves = two_waves && pass == 0 ? 2 : 1;
-        if (binned && pass == 0) n_waves = 0;
 #ifdef SKM_TUNING                                    // (tuning builds only: scripts/build_variant.sh)
         if (n_waves > 1)
             if (const char *e = getenv("SKM_CLASS_WAVES")) {
@@ -1014,7 +987,7 @@ int map_batch_resident(skm_mapper *m, const uint8_t *d_bases, const int64_t *d_o
         for (int wave = 0; wave < n_waves; ++wave) {
             const int64_t w0 = n_waves == 1 || wave == 0 ? 0 : n_units * cuts[wave - 1] / 16;
             const int64_t w1 = n_waves == 1 ? n_units : n_units * cuts[wave] / 16;
-            MapBatch part = cb;                  // records [w0, w1) of the batch
+            MapBatch part = b;                   // records [w0, w1) of the batch
             part.rec_unit += w0; part.rec_key += w0; part.rec_tuple += w0;
             part.n_units = w1 - w0;
             launch_class_insert(m->t, part, unit_base, m->unit_slot.p + w0, pass > 0, pass == 0 && wave == 0, m->stream);
@@ -1107,7 +1080,6 @@ extern "C" int skm_mapper_destroy(skm_mapper *m)
     m->workspace.release(); m->unit_begin.release(); m->unit_end.release();
     m->rec_unit.release(); m->unit_anchor.release(); m->rec_tuple.release();
     m->unit_slot.release(); m->rec_key.release(); m->unit_entries.release(); m->batch_ctl.release();
-    m->bin_words.release(); m->bin_unit.release(); m->bin_ids.release(); m->bin_key.release(); m->bin_tuple.release();
     for (auto &e : m->ev) (void)hipEventDestroy(e);
     if (m->pinned) (void)hipHostFree(m->pinned);
     pool_stream_release(m->stream);

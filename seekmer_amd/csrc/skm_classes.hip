@@ -23,7 +23,6 @@
 // finder happens to see already set by a creator of the same launch is treated
 // as not yet there: its arena offset is not below the launch's starting cursor).
 #include "skm_kernels.h"
-#include <cstdlib>
 #include "../../include/seekmer_hip.h"
 
 namespace skm {
@@ -294,293 +293,6 @@ class_insert_kernel(ClassTable t, MapBatch b, int64_t unit_base, int64_t *unit_s
         atomicAdd(t.n_units, (unsigned long long)b.n_units);
 }
 
-// ---------------------------------------------------------------- counting by slot range
-// class_insert_kernel sends one scattered device-scope atomic per record to the table (10 M of them at
-// 23 G/s were half of its time) and reads every record's tuple from wherever the map kernel's waves
-// left it.  For a large batch the records are therefore first BINNED by the slot range their key
-// hashes to (bin = home slot >> BIN_SHIFT: BIN_RANGE consecutive slots, 128 KB of the table), their
-// tuple ids moving with them, and one block per bin then counts in LDS:
-//   bin_count    a block's histogram of its chunk of records (LDS) -> bin totals (records, ids)
-//   bin_scan     one block: exclusive prefix sums = where every bin starts
-//   bin_scatter  every block takes its chunk's share of every bin with one atomicAdd per bin and
-//                counter, then writes records and ids there (runs of a few dozen per bin and block:
-//                the stores merge in L2)
-//   bin_insert   one block per bin: the probes read a 128 KB piece of the table (L2-resident),
-//                count / first-seen updates go to LDS arrays over the bin's slot range and reach the
-//                table with ONE atomic per touched slot at the end; a class is created (CAS) and
-//                committed as in class_insert_kernel; and since all records of a class meet in one
-//                block, a record that finds a class this block committed in an EARLIER iteration
-//                compares its tuple on the spot (workgroup-scope ordering), reading its own ids
-//                from the bin's contiguous id area -- class_verify is left with the finds of a
-//                class's first iteration and with probes that ran into a neighbour's range.
-// Results are those of class_insert_kernel (the table is the same open-addressing table; counts and
-// minima commute).  Small batches, small tables and the retry of deferred records take the plain kernel.
-constexpr int BIN_SHIFT = 12;
-constexpr int BIN_RANGE = 1 << BIN_SHIFT;            // slots per bin
-constexpr int BIN_MARGIN = CLASS_PROBE_LIMIT;        // probes may run this far into the next bin's range
-constexpr int BIN_MAX = CLASS_BIN_MAX;               // bins (LDS histograms of bin_count / bin_scatter)
-constexpr int BIN_CHUNK_BLOCKS = 1024;
-
-__device__ __forceinline__ int bin_of(unsigned long long key, uint64_t slot_mask)
-{
-    return (int)((key & slot_mask) >> BIN_SHIFT);
-}
-
-__global__ void __launch_bounds__(256)
-class_bin_count_kernel(MapBatch b, uint64_t slot_mask, BinPlan plan)
-{
-    extern __shared__ unsigned int lds[];             // [n_bins] records, [n_bins] ids
-    unsigned int *cnt = lds, *ids = lds + plan.n_bins;
-    for (int i = threadIdx.x; i < 2 * plan.n_bins; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
-    const int64_t per = (b.n_units + gridDim.x - 1) / gridDim.x;
-    const int64_t first = blockIdx.x * per, last = min(b.n_units, first + per);
-    unsigned int unaligned = 0;
-    for (int64_t r = first + threadIdx.x; r < last; r += blockDim.x) {
-        const unsigned long long key = b.rec_key[r];
-        if (key == 0) { ++unaligned; continue; }
-        const int bin = bin_of(key, slot_mask);
-        atomicAdd(&cnt[bin], 1u);
-        atomicAdd(&ids[bin], (unsigned int)(b.rec_tuple[r] >> 40));
-    }
-    for (int d = 32; d > 0; d >>= 1) unaligned += __shfl_xor(unaligned, d, 64);
-    if ((threadIdx.x & 63) == 0 && unaligned) atomicAdd(plan.unaligned, (unsigned long long)unaligned);
-    __syncthreads();
-    for (int i = threadIdx.x; i < plan.n_bins; i += blockDim.x) {
-        if (cnt[i]) atomicAdd(&plan.count[i], cnt[i]);
-        if (ids[i]) atomicAdd(&plan.id_count[i], ids[i]);
-    }
-}
-
-// one block of 1024: exclusive prefix sums over the bins; the counters become the scatter cursors
-__global__ void __launch_bounds__(1024)
-class_bin_scan_kernel(BinPlan plan)
-{
-    __shared__ unsigned int part[2][1024];
-    constexpr int PER = BIN_MAX / 1024;
-    unsigned int c[PER], d[PER], sum_c = 0, sum_d = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = threadIdx.x * PER + k;
-        c[k] = i < plan.n_bins ? plan.count[i] : 0;
-        d[k] = i < plan.n_bins ? plan.id_count[i] : 0;
-        sum_c += c[k]; sum_d += d[k];
-    }
-    part[0][threadIdx.x] = sum_c; part[1][threadIdx.x] = sum_d;
-    __syncthreads();
-    for (int step = 1; step < 1024; step <<= 1) {
-        unsigned int a = 0, e = 0;
-        if ((int)threadIdx.x >= step) { a = part[0][threadIdx.x - step]; e = part[1][threadIdx.x - step]; }
-        __syncthreads();
-        part[0][threadIdx.x] += a; part[1][threadIdx.x] += e;
-        __syncthreads();
-    }
-    unsigned int at_c = part[0][threadIdx.x] - sum_c, at_d = part[1][threadIdx.x] - sum_d;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = threadIdx.x * PER + k;
-        if (i < plan.n_bins) {
-            plan.start[i] = at_c; plan.id_start[i] = at_d;
-            plan.count[i] = at_c; plan.id_count[i] = at_d;        // cursors
-        }
-        at_c += c[k]; at_d += d[k];
-    }
-    if (threadIdx.x == 1023) { plan.start[plan.n_bins] = part[0][1023]; plan.id_start[plan.n_bins] = part[1][1023]; }
-}
-
-__global__ void __launch_bounds__(256)
-class_bin_scatter_kernel(MapBatch b, uint64_t slot_mask, BinPlan plan, int32_t *out_unit, uint64_t *out_key,
-                         unsigned long long *out_tuple, int32_t *out_ids)
-{
-    extern __shared__ unsigned int lds[];             // [n_bins] x { records, ids, record base, id base }
-    unsigned int *cnt = lds, *ids = lds + plan.n_bins, *base = lds + 2 * plan.n_bins, *id_base = lds + 3 * plan.n_bins;
-    for (int i = threadIdx.x; i < 2 * plan.n_bins; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
-    const int64_t per = (b.n_units + gridDim.x - 1) / gridDim.x;
-    const int64_t first = blockIdx.x * per, last = min(b.n_units, first + per);
-    for (int64_t r = first + threadIdx.x; r < last; r += blockDim.x) {
-        const unsigned long long key = b.rec_key[r];
-        if (key == 0) continue;
-        const int bin = bin_of(key, slot_mask);
-        atomicAdd(&cnt[bin], 1u);
-        atomicAdd(&ids[bin], (unsigned int)(b.rec_tuple[r] >> 40));
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < plan.n_bins; i += blockDim.x) {
-        base[i] = cnt[i] ? atomicAdd(&plan.count[i], cnt[i]) : 0;
-        id_base[i] = ids[i] ? atomicAdd(&plan.id_count[i], ids[i]) : 0;
-        cnt[i] = 0; ids[i] = 0;
-    }
-    __syncthreads();
-    for (int64_t r = first + threadIdx.x; r < last; r += blockDim.x) {
-        const unsigned long long key = b.rec_key[r];
-        if (key == 0) continue;
-        const unsigned long long tuple = b.rec_tuple[r];
-        const unsigned int n = (unsigned int)(tuple >> 40);
-        const int bin = bin_of(key, slot_mask);
-        const unsigned int at = base[bin] + atomicAdd(&cnt[bin], 1u);
-        const unsigned int id_at = id_base[bin] + atomicAdd(&ids[bin], n);
-        out_key[at] = key;
-        out_unit[at] = b.rec_unit[r];
-        out_tuple[at] = (unsigned long long)id_at | ((unsigned long long)n << 40);
-        const int32_t *from = b.unit_entries + (tuple & ((1ULL << 40) - 1));
-        for (unsigned int i = 0; i < n; ++i) out_ids[id_at + i] = from[i];
-    }
-}
-
-// One block per bin over the binned records (`b` holds them: rec_* by binned place, unit_entries =
-// the binned ids).  unit_slot (by binned place) leaves -1 for a record that needs nothing more, the
-// slot for class_verify, -2 for a deferred one.
-constexpr int BIN_WIDTH = 4;
-__global__ void __launch_bounds__(256)
-class_bin_insert_kernel(ClassTable t, MapBatch b, BinPlan plan, int64_t unit_base, int64_t n_batch_units, int64_t *unit_slot)
-{
-    const long long committed = (long long)*t.arena_committed;
-    __shared__ unsigned int s_new_classes[4], s_new_ids[4];
-    __shared__ unsigned long long s_base[2];
-    __shared__ unsigned int l_count[BIN_RANGE + BIN_MARGIN], l_min[BIN_RANGE + BIN_MARGIN];
-    // (bit i: local slot i was committed by this block in an earlier iteration)
-    __shared__ unsigned int l_mine[(BIN_RANGE + BIN_MARGIN + 31) / 32];
-    for (int i = threadIdx.x; i < BIN_RANGE + BIN_MARGIN; i += blockDim.x) { l_count[i] = 0; l_min[i] = 0xffffffffu; }
-    for (int i = threadIdx.x; i < (BIN_RANGE + BIN_MARGIN + 31) / 32; i += blockDim.x) l_mine[i] = 0;
-    __syncthreads();
-    const int bin = blockIdx.x;
-    const uint64_t bin_base = (uint64_t)bin << BIN_SHIFT;
-    const int64_t first = plan.start[bin], last = plan.start[bin + 1];
-    bool all_same = true;
-    for (int64_t r0 = first; r0 < last; r0 += BIN_WIDTH * 256) {
-        unsigned long long key[BIN_WIDTH], mine_at[BIN_WIDTH];
-        int64_t made_slot[BIN_WIDTH], made_local[BIN_WIDTH];
-        ulonglong2 head[BIN_WIDTH];
-        long long tuple_word[BIN_WIDTH];
-        int32_t unit_of[BIN_WIDTH];
-        bool live[BIN_WIDTH];
-#pragma unroll
-        for (int k = 0; k < BIN_WIDTH; ++k) {
-            const int64_t r = r0 + k * 256 + threadIdx.x;
-            made_slot[k] = -1; made_local[k] = -1;
-            live[k] = r < last;
-            key[k] = live[k] ? b.rec_key[r] : 0;
-            unit_of[k] = live[k] ? b.rec_unit[r] : 0;
-            mine_at[k] = live[k] ? b.rec_tuple[r] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < BIN_WIDTH; ++k) {
-            const ClassSlot *home = &t.slots[key[k] & t.slot_mask];
-            head[k] = live[k] ? *reinterpret_cast<const ulonglong2 *>(home) : ulonglong2{0ULL, 0ULL};
-            tuple_word[k] = live[k] ? home->tuple : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < BIN_WIDTH; ++k) {
-            if (!live[k]) continue;
-            const int64_t r = r0 + k * 256 + threadIdx.x;
-            int64_t where = -1;
-            bool claimed;
-            unsigned long long seen = ~0ULL;
-            long long stored = -1;
-            const uint64_t slot = probe_claim_from(t, key[k], head[k], tuple_word[k], claimed, CLASS_PROBE_LIMIT, seen, stored);
-            if (slot == ~0ULL) {
-                atomicAdd(t.n_deferred, 1ULL);
-                where = -2;
-            } else {
-                const uint64_t local = slot - bin_base;            // (a probe that wrapped around the table: huge)
-                const bool in_range = local < (uint64_t)(BIN_RANGE + BIN_MARGIN);
-                if (claimed) { made_slot[k] = (int64_t)slot; made_local[k] = in_range ? (int64_t)local : -1; }
-                if (in_range) {
-                    atomicAdd(&l_count[local], 1u);
-                    atomicMin(&l_min[local], (unsigned int)unit_of[k]);
-                } else {
-                    atomicAdd(&t.slots[slot].count, 1ULL);
-                    atomicMin(&t.slots[slot].first_seen, (unsigned long long)(unit_base + unit_of[k]));
-                }
-                where = claimed ? -1 : (int64_t)slot;
-                // a tuple that is in the arena since an earlier launch, or that THIS block stored in an
-                // earlier iteration (block barrier + workgroup-scope fence below): compare now
-                bool known = stored >= 0 && tuple_offset(stored) < committed;
-                if (!known && !claimed && in_range && ((l_mine[local >> 5] >> (local & 31)) & 1u)) {
-                    stored = *(volatile long long *)&t.slots[slot].tuple;
-                    known = stored >= 0;
-                }
-                if (known) {
-                    const int n = (int)(mine_at[k] >> 40);
-                    bool same = tuple_len(stored) == n;
-                    if (same) {
-                        const int32_t *mine = b.unit_entries + (mine_at[k] & ((1ULL << 40) - 1));
-                        const int32_t *ref = t.arena + tuple_offset(stored);
-                        for (int i = 0; same && i < n; ++i) same = (uint32_t)ref[i] == unsigned_id(mine[i]);
-                    }
-                    all_same &= same;
-                    where = -1;
-                }
-            }
-            unit_slot[r] = where;
-        }
-        // ---- the block's new classes of this iteration (as class_insert_kernel)
-        unsigned int my_classes = 0, my_ids = 0;
-#pragma unroll
-        for (int k = 0; k < BIN_WIDTH; ++k)
-            if (made_slot[k] >= 0) { ++my_classes; my_ids += (unsigned int)(mine_at[k] >> 40); }
-        unsigned int before_classes = my_classes, before_ids = my_ids;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int c = __shfl_up(before_classes, d, 64), i = __shfl_up(before_ids, d, 64);
-            if (lane >= d) { before_classes += c; before_ids += i; }
-        }
-        if (lane == 63) { s_new_classes[wave] = before_classes; s_new_ids[wave] = before_ids; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned int classes = s_new_classes[0] + s_new_classes[1] + s_new_classes[2] + s_new_classes[3];
-            const unsigned int ids = s_new_ids[0] + s_new_ids[1] + s_new_ids[2] + s_new_ids[3];
-            s_base[0] = s_base[1] = 0;
-            if (classes) {
-                s_base[0] = atomicAdd(t.n_listed, (unsigned long long)classes);
-                s_base[1] = atomicAdd(t.arena_cursor, (unsigned long long)ids);
-                atomicAdd(t.n_classes, (unsigned long long)classes);
-            }
-        }
-        __syncthreads();
-        if (my_classes) {
-            long long registry = (long long)s_base[0] + (before_classes - my_classes);
-            long long at = (long long)s_base[1] + (before_ids - my_ids);
-            for (int w = 0; w < wave; ++w) { registry += s_new_classes[w]; at += s_new_ids[w]; }
-#pragma unroll
-            for (int k = 0; k < BIN_WIDTH; ++k) {
-                if (made_slot[k] < 0) continue;
-                const int n = (int)(mine_at[k] >> 40);
-                if (at + n > t.arena_capacity || registry >= t.class_list_capacity) {
-                    atomicExch(t.error, SKM_ERR_STATE);
-                } else {
-                    const int32_t *entries = b.unit_entries + (mine_at[k] & ((1ULL << 40) - 1));
-                    for (int i = 0; i < n; ++i) t.arena[at + i] = (int32_t)unsigned_id(entries[i]);
-                    t.slots[made_slot[k]].tuple = tuple_pack(at, n);
-                    t.class_list[registry] = made_slot[k];
-                    if (made_local[k] >= 0) atomicOr(&l_mine[made_local[k] >> 5], 1u << (made_local[k] & 31));
-                }
-                at += n;
-                ++registry;
-            }
-        }
-        // the tuples and tuple words stored above are read by this block's next iteration
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    if (!all_same) atomicExch(t.error, SKM_ERR_COLLISION);
-    __syncthreads();
-    for (int i = threadIdx.x; i < BIN_RANGE + BIN_MARGIN; i += blockDim.x) {
-        if (l_count[i] == 0) continue;
-        ClassSlot *slot = &t.slots[bin_base + i];
-        atomicAdd(&slot->count, (unsigned long long)l_count[i]);
-        atomicMin(&slot->first_seen, (unsigned long long)(unit_base + (int64_t)l_min[i]));
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(t.n_units, (unsigned long long)n_batch_units);
-        const unsigned long long unaligned = *plan.unaligned;
-        if (unaligned) atomicAdd(t.n_unaligned, unaligned);
-    }
-}
-
 // between the launches of a batch: what has been committed so far is published for the next
 // launch's on-the-spot compares (and, once per batch, the batch histogram is merged:
 // merge_fragment_lengths, mapper.py:106-115)
@@ -765,44 +477,6 @@ void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_ba
     hipLaunchKernelGGL(class_insert_kernel, dim3(grid_for(b.n_units, SKM_CLASS_INSERT_BLOCKS)), dim3(256), 0, stream, t, b,
                        unit_base, unit_slot, retry_deferred);
     hipLaunchKernelGGL(class_totals_kernel, dim3(8), dim3(256), 0, stream, t, merge_fld ? b.fld : nullptr);
-}
-
-bool class_binning_applies(const ClassTable &t, int64_t n_units)
-{
-    const uint64_t n_slots = t.slot_mask + 1;
-    static const bool always = getenv("SKM_TEST_CLASS_BINS") != nullptr;    // test hook: bin whatever the sizes allow
-    if (always) return n_units >= 1 && n_units < (1LL << 32) && n_slots >= (1u << BIN_SHIFT) && (n_slots >> BIN_SHIFT) <= BIN_MAX;
-    return n_units >= (1 << 20) && n_units < (1LL << 32) && n_slots >= (256u << BIN_SHIFT) && (n_slots >> BIN_SHIFT) <= BIN_MAX;
-}
-
-// bin the batch's records into (out_unit, out_key, out_tuple, out_ids); `words`: CLASS_BIN_WORDS
-// unsigned ints of device scratch (zeroed here).  Returns the plan for launch_class_bin_insert.
-BinPlan launch_class_bin(const ClassTable &t, const MapBatch &b, unsigned int *words, int32_t *out_unit,
-                         uint64_t *out_key, unsigned long long *out_tuple, int32_t *out_ids, hipStream_t stream)
-{
-    BinPlan plan{};
-    plan.n_bins = (int)((t.slot_mask + 1) >> BIN_SHIFT);
-    plan.count = words;
-    plan.id_count = words + BIN_MAX;
-    plan.start = words + 2 * BIN_MAX;
-    plan.id_start = words + 3 * BIN_MAX + 2;
-    plan.unaligned = reinterpret_cast<unsigned long long *>(words + 4 * BIN_MAX + 4);
-    (void)hipMemsetAsync(words, 0, (4 * BIN_MAX + 8) * sizeof(unsigned int), stream);
-    hipLaunchKernelGGL(class_bin_count_kernel, dim3(BIN_CHUNK_BLOCKS), dim3(256), 2 * plan.n_bins * sizeof(unsigned int),
-                       stream, b, t.slot_mask, plan);
-    hipLaunchKernelGGL(class_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, plan);
-    hipLaunchKernelGGL(class_bin_scatter_kernel, dim3(BIN_CHUNK_BLOCKS), dim3(256), 4 * plan.n_bins * sizeof(unsigned int),
-                       stream, b, t.slot_mask, plan, out_unit, out_key, out_tuple, out_ids);
-    return plan;
-}
-
-// `binned`: the MapBatch over the binned arrays (n_units = the batch's units; the bins hold the aligned ones)
-void launch_class_bin_insert(const ClassTable &t, const MapBatch &binned, const BinPlan &plan, int64_t unit_base,
-                             int64_t *unit_slot, bool merge_fld, hipStream_t stream)
-{
-    hipLaunchKernelGGL(class_bin_insert_kernel, dim3(plan.n_bins), dim3(256), 0, stream, t, binned, plan, unit_base,
-                       binned.n_units, unit_slot);
-    hipLaunchKernelGGL(class_totals_kernel, dim3(8), dim3(256), 0, stream, t, merge_fld ? binned.fld : nullptr);
 }
 
 void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,

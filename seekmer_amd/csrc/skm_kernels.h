@@ -114,25 +114,6 @@ void launch_class_insert(const ClassTable &t, const MapBatch &b, int64_t unit_ba
                          int64_t *unit_slot, bool retry_deferred, bool merge_fld, hipStream_t stream);
 void launch_class_verify(const ClassTable &t, const MapBatch &b, const int64_t *unit_slot,
                          hipStream_t stream);
-// Counting by slot range (skm_classes.hip): a large batch's records are binned by the table range
-// their key hashes to and one block per bin counts in LDS.  CLASS_BIN_WORDS unsigned ints of scratch.
-struct BinPlan {
-    int n_bins;                   // table slots >> 12
-    unsigned int *count;          // [n_bins] records per bin, then the scatter cursors
-    unsigned int *id_count;       // [n_bins] ids per bin, then the scatter cursors
-    unsigned int *start;          // [n_bins + 1]
-    unsigned int *id_start;       // [n_bins + 1]
-    unsigned long long *unaligned;   // records with the empty tuple (not binned)
-};
-constexpr int CLASS_BIN_MAX = 4096;             // bins: 64 KB of LDS histograms in the scatter kernel
-constexpr int CLASS_BIN_WORDS = 4 * CLASS_BIN_MAX + 8;
-bool class_binning_applies(const ClassTable &t, int64_t n_units);
-// bin the batch's records into (out_unit, out_key, out_tuple, out_ids); `words`: CLASS_BIN_WORDS of scratch
-BinPlan launch_class_bin(const ClassTable &t, const MapBatch &b, unsigned int *words, int32_t *out_unit,
-                         uint64_t *out_key, unsigned long long *out_tuple, int32_t *out_ids, hipStream_t stream);
-// `binned`: the MapBatch over the binned arrays (n_units = the batch's units; unit_slot by binned place)
-void launch_class_bin_insert(const ClassTable &t, const MapBatch &binned, const BinPlan &plan, int64_t unit_base,
-                             int64_t *unit_slot, bool merge_fld, hipStream_t stream);
 void launch_class_rehash(const ClassTable &from, const ClassTable &to, int64_t *forward,
                          hipStream_t stream);
 void launch_slot_remap(int64_t *slots, int64_t n, const int64_t *forward, hipStream_t stream);

@@ -1554,63 +1554,3 @@ def test_tables_merge_on_the_device(oracle, native_libs, chr21, chr21_oracle_ind
     for got, want in zip(by_host[0].export(), reference):
         np.testing.assert_array_equal(got, want)
 
-
-def test_classes_counted_by_slot_range(oracle, native_libs):
-    """Large batches are counted by slot range (records binned by the table range their key hashes
-    to, one block per bin counting in LDS: skm_classes.hip) -- here forced on for a batch the oracle
-    handles (SKM_TEST_CLASS_BINS: a separate process, the switch is read once): the same table as the
-    plain kernel's and the oracle's, for one batch, for batches that accumulate (the second one meets
-    every class of the first: the on-the-spot compares), with unaligned units, and bit-identical TPM."""
-    import subprocess
-    import sys
-    code = r"""
-import numpy as np, sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from oracle import oracle as O
-from seekmer_amd import synth, index_builder, mapper, common, infer
-ids, pool, tx_offsets = synth.transcriptome(5, 300)
-index = index_builder.build_pooled(ids, pool, tx_offsets)
-oindex = O.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets, lengths=np.diff(tx_offsets))
-n = 150000
-bases, offsets = synth.reads(5, pool, tx_offsets, 0, n, 100, True)
-junk = np.frombuffer(bytes(np.random.default_rng(1).integers(0, 4, 200 * 2000).astype(np.uint8)).translate(
-    bytes.maketrans(bytes(range(4)), b'ACGT')), dtype=np.uint8)
-bases = np.concatenate([bases[:-1], junk, np.zeros(1, np.uint8)])       # 1000 pairs that align nowhere
-offsets = np.concatenate([offsets, offsets[-1] + np.arange(1, 2001, dtype=np.int64) * 200])
-n += 1000
-fld = np.zeros(2000, dtype=np.int64)
-expected = O.map_batch(oindex, bases, offsets, n, True, fld)
-classes = O.Classes(); classes.update(expected)
-want = classes.export()
-def check(result, times=1):
-    got = result.export()
-    assert np.array_equal(got[4], fld * times)
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2] * times)
-    assert result.sizes()[2] == classes.unaligned * times and result.sizes()[3] == n * times
-whole = mapper.MapResult(index)
-rm = mapper.ReadMapper(index, whole)
-rm.map_batch(common.ReadBatch(n, bases, offsets, True))
-check(whole)
-tpm, iters = infer.quantify_resident(whole, return_iters=True)
-rm.map_batch(common.ReadBatch(n, bases, offsets, True))          # every class known: compared on the spot
-got = whole.export()
-assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2] * 2)
-split = mapper.MapResult(index)
-rs = mapper.ReadMapper(index, split)
-for lo, hi in ((0, 70000), (70000, 70001), (70001, n)):
-    rs.map_batch(common.ReadBatch(hi - lo, bases, np.ascontiguousarray(offsets[2 * lo:2 * hi + 1]), True))
-check(split)
-tpm2, iters2 = infer.quantify_resident(split, return_iters=True)
-assert iters2 == iters and np.array_equal(tpm2, tpm)
-print('binned' if 'bins' in sys.argv[1] else 'plain', whole.sizes(), iters, float(tpm.sum()))
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for mode in ('bins', 'plain'):
-        env = dict(os.environ)
-        env.pop('SKM_TEST_CLASS_BINS', None)
-        if mode == 'bins':
-            env['SKM_TEST_CLASS_BINS'] = '1'
-        done = subprocess.run([sys.executable, '-c', code, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        assert done.returncode == 0, done.stderr.decode()[-3000:]
-        outs.append(done.stdout.decode().strip().splitlines()[-1].split(' ', 1))
-    assert outs[0][0] == 'binned' and outs[1][0] == 'plain' and outs[0][1] == outs[1][1]
