@@ -392,6 +392,13 @@ int skm_fastq_close(skm_fastq *reader);
  * file (default 0: a mapping goes when its last reader closes; a caller that reads the same files
  * again and again -- a benchmark's passes -- saves the page-table set-up of the later passes). */
 int skm_fastq_cache_bytes(int64_t bytes);
+/* The page tables of the input ahead of its reader: map the files now and touch their pages from
+ * n_threads helper threads -- for a run that knows its FASTQ files while it is still loading the index
+ * (setting up the page tables of the text costs as much as parsing it).  A reader opened before
+ * _finish finds the mappings in place; _finish stops the helpers and drops what nobody has open. */
+typedef struct skm_fastq_prefault skm_fastq_prefault;
+int skm_fastq_prefault_start(const char *const *paths, int n_paths, int n_threads, skm_fastq_prefault **out);
+int skm_fastq_prefault_finish(skm_fastq_prefault *handle);
 
 /* ---- FASTQ text -> 2-bit reads on the host (skm_packed_reads, above) ------------------------- */
 /* feed_single_ended_reads / feed_pair_ended_reads (seekmer/common.py:126-197) for plain (not

@@ -18,6 +18,12 @@ cd /tmp && export TMPDIR=/tmp
 for k in 1 2; do
   python3 $ROOT/bench.py --cold-child /dev/shm/skm_cold_index.npz /dev/shm/skm_cold_1.fastq /dev/shm/skm_cold_2.fastq 2>> $OUT/plain.err | tail -1
 done | tee $OUT/plain.log
+for threads in 14 8; do
+  SKM_COLD_PARSE_ONLY=1 python3 $ROOT/bench.py --cold-child /dev/shm/skm_cold_index.npz /dev/shm/skm_cold_1.fastq /dev/shm/skm_cold_2.fastq --parse-threads $threads 2>> $OUT/plain.err | tail -1
+done | tee $OUT/parse_only.log
+for mb in 4 16; do
+  python3 $ROOT/bench.py --cold-child /dev/shm/skm_cold_index.npz /dev/shm/skm_cold_1.fastq /dev/shm/skm_cold_2.fastq --e2e-chunk-mb $mb 2>> $OUT/plain.err | tail -1
+done | tee $OUT/chunks.log
 timeout -k 10 300 rocprofv3 --hip-trace --kernel-trace --stats -d $OUT/prof --output-format csv -- \
     python3 $ROOT/bench.py --cold-child /dev/shm/skm_cold_index.npz /dev/shm/skm_cold_1.fastq /dev/shm/skm_cold_2.fastq > $OUT/run.log 2>&1
 find $OUT/prof -name "*hip_api_stats.csv" -exec cp {} $OUT/hip_api_stats.csv \;

@@ -149,6 +149,8 @@ HOST_SYMBOLS = {
     'skm_fastq_packed_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_packed_next': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PackedReads)]),
     'skm_fastq_packed_stats': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
+    'skm_fastq_prefault_start': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int, c_void_pp]),
+    'skm_fastq_prefault_finish': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_fastq_packed_estimate': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),
     'skm_fastq_packed_close': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_pack_reads': (ctypes.c_int, [ctypes.c_void_p, c_i64p, c_i64, ctypes.c_int32, ctypes.c_void_p,

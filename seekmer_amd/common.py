@@ -582,6 +582,39 @@ class PackedReads:
                                paired=paired)
 
 
+class Prefault:
+    """The page tables of plain FASTQ files set up ahead of their reader (skm_fastq_prefault_*): helper
+    threads map the files and touch their pages while the caller still loads its index.  ``finish()``
+    (or leaving the ``with`` block) once the reader has opened the files -- or never needed them."""
+
+    def __init__(self, paths, threads=4):
+        self.handle = ctypes.c_void_p()
+        paths = [pathlib.Path(p) for p in paths]
+        if not paths or not PackedReadFeeder.eligible(paths):
+            return
+        names = [str(p).encode() for p in paths]
+        array = (ctypes.c_char_p * len(names))(*names)
+        if _native.host().skm_fastq_prefault_start(array, len(names), max(1, int(threads)), ctypes.byref(self.handle)) != 0:
+            self.handle = ctypes.c_void_p()           # (only an optimisation: the reader reports what is wrong)
+
+    def finish(self):
+        if self.handle:
+            _native.host().skm_fastq_prefault_finish(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.finish()
+
+    def __del__(self):
+        try:
+            self.finish()
+        except Exception:
+            pass
+
+
 class PackedReadFeeder:
     """Plain FASTQ files straight to PackedReads pieces in one pass over the text
     (skm_fastq_packed_*): the reference's feeders (seekmer/common.py:126-197) for the mapper's own

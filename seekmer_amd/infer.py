@@ -65,12 +65,17 @@ def _run(ranks, start_time, index_path, output_path, fastq_paths, job_count, sav
     # (the readers' threads page-lock against THIS GPU; their arena is page-locked by a helper thread
     # from here on, under the index load and upload)
     _native.check(_native.hip().skm_pinned_set_device(device))
-    index = common.KMerIndex.load(index_path)
-    index.device_handle(device)
-    _LOG.info('Mapping all reads')
     read_feeder = _feeder(fastq_paths, not single_ended, parse_threads, ranks.shard, save_readmap)
-    map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
-                                  readmap=readmap, debug=debug, device=device)
+    # (the one-pass reader maps the text: its page tables are set up by helper threads while the index loads)
+    ahead = common.Prefault(fastq_paths if isinstance(read_feeder, common.PackedReadFeeder) else [], threads=4)
+    try:
+        index = common.KMerIndex.load(index_path)
+        index.device_handle(device)
+        _LOG.info('Mapping all reads')
+        map_result = mapper.map_reads(index, read_feeder, job_count=job_count,
+                                      readmap=readmap, debug=debug, device=device)
+    finally:
+        ahead.finish()
     _LOG.info('Mapped all reads')
     if bootstrap > 0:
         _check_resample_limit(map_result, ranks)
