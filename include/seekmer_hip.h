@@ -328,6 +328,13 @@ int skm_comm_unique_id(void *id128);                 /* rank 0: 128-byte id, sin
 int skm_comm_create(int device, const void *id128, int rank, int world, skm_comm **out);
 int skm_comm_count(skm_comm *comm, int *count);     /* ncclCommCount: ranks RCCL itself sees */
 int skm_comm_destroy(skm_comm *comm);
+/* The table hand-over of SURVEY.md 8(e).1 over xGMI: `send`'s table goes to rank send_to as it lies
+ * in HBM (ncclSend of skm_mapper_device_table's arrays), the table rank recv_from sends is received
+ * into HBM and merged into `recv` by key (skm_mapper_merge_device) -- no host copy, no host sort.
+ * Either side may be NULL.  Matching calls: rank r: (mapper, 0, NULL, -1), rank 0: (NULL, -1,
+ * mapper, r) for every r > 0 in turn.  Experimental: no multi-GPU node has run it; a rank sending
+ * to itself is what the one-GPU test exercises. */
+int skm_mapper_exchange_tables(skm_mapper *send, int send_to, skm_mapper *recv, int recv_from, skm_comm *comm);
 int skm_quant_set_comm(skm_quant *quant, skm_comm *comm);   /* NULL detaches */
 
 /* One sample, mapper table -> TPM, without leaving the device: MapResult.effective_lengths

@@ -120,6 +120,8 @@ HIP_SYMBOLS = {
                                        c_void_pp]),
     'skm_comm_count': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     'skm_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'skm_mapper_exchange_tables': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_void_p]),
     'skm_quant_set_comm': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'skm_quant_infer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f64p, c_i64, ctypes.c_double,
                                        ctypes.c_double, c_i64, c_f64p, c_f64p, c_i64p]),

@@ -2102,6 +2102,10 @@ struct Rccl {
     int (*CommDestroy)(void *) = nullptr;
     int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;      // (table hand-over; optional)
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
 };
 struct UniqueId { char internal[128]; };
 typedef int (*comm_init_fn)(void **, int, UniqueId, int);
@@ -2121,13 +2125,17 @@ int load_rccl()
     g_rccl.CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
     g_rccl.CommCount = (int (*)(void *, int *))dlsym(lib, "ncclCommCount");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    g_rccl.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclSend");
+    g_rccl.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(lib, "ncclRecv");
+    g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
     if (!g_rccl.GetUniqueId || !g_comm_init || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(SKM_ERR_COMM, "librccl.so lacks a required symbol");
     g_rccl.lib = lib;
     return SKM_OK;
 }
 
-constexpr int NCCL_FLOAT64 = 8, NCCL_UINT64 = 5, NCCL_SUM = 0;
+constexpr int NCCL_FLOAT64 = 8, NCCL_UINT64 = 5, NCCL_INT32 = 2, NCCL_SUM = 0;
 
 #define NCCL_TRY(call)                                                                   \
     do {                                                                                 \
@@ -2770,6 +2778,86 @@ extern "C" int skm_comm_count(skm_comm *c, int *count)
     if (!g_rccl.CommCount) return fail(SKM_ERR_COMM, "librccl.so lacks ncclCommCount");
     NCCL_TRY(g_rccl.CommCount(c->comm, count));
     return SKM_OK;
+}
+
+// SURVEY 8(e).1 over xGMI: a mapper's table goes from GPU to GPU as it lies in HBM
+// (skm_mapper_device_table's arrays, ncclSend / ncclRecv) and is merged by key on the receiving GPU
+// (class_merge_kernel over the received arrays): no host copy, no host sort.  One call does both
+// directions so that a rank may pair a send with a receive (two ranks swapping, or -- the one-GPU
+// test -- a rank sending to itself): first the sizes (a header of eight words), then the arrays.
+extern "C" int skm_mapper_exchange_tables(skm_mapper *send, int send_to, skm_mapper *recv, int recv_from, skm_comm *comm)
+{
+    if (!comm || (!send && !recv)) return fail(SKM_ERR_ARG, "NULL argument");
+    if ((send && send_to < 0) || (recv && recv_from < 0) || send_to >= comm->world || recv_from >= comm->world)
+        return fail(SKM_ERR_ARG, "peer rank outside the communicator");
+    if ((send && send->ix->device != comm->device) || (recv && recv->ix->device != comm->device))
+        return fail(SKM_ERR_ARG, "communicator and mapper live on different GPUs");
+    SKM_TRY(load_rccl());
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return fail(SKM_ERR_COMM, "librccl.so lacks ncclSend / ncclRecv");
+    SKM_TRY(set_device(comm->device));
+    skm_device_table out{};
+    if (send) SKM_TRY(skm_mapper_device_table(send, &out));            // (waits for what the mapper has queued)
+    hipStream_t stream = nullptr;
+    HIP_TRY(pool_stream_acquire(&stream));
+    DBuf<unsigned long long> header, fld, first_seen;
+    DBuf<int64_t> start, len;
+    DBuf<double> count;
+    DBuf<int32_t> ids;
+    auto undo = on_exit([&]() {
+        (void)hipStreamSynchronize(stream);
+        header.release(); fld.release(); first_seen.release(); start.release(); len.release(); count.release(); ids.release();
+        pool_stream_release(stream);
+    });
+    SKM_TRY(header.ensure(16));
+    unsigned long long words[16] = {(unsigned long long)out.n_classes, (unsigned long long)out.n_ids,
+                                    (unsigned long long)out.unaligned, (unsigned long long)out.units,
+                                    (unsigned long long)out.first_seen_bound, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(header.p, words, 8 * 8, hipMemcpyHostToDevice, stream));
+    NCCL_TRY(g_rccl.GroupStart());
+    if (send) NCCL_TRY(g_rccl.Send(header.p, 8, NCCL_UINT64, send_to, comm->comm, stream));
+    if (recv) NCCL_TRY(g_rccl.Recv(header.p + 8, 8, NCCL_UINT64, recv_from, comm->comm, stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipMemcpyAsync(words + 8, header.p + 8, 8 * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    skm_device_table in{};
+    in.device = comm->device;
+    if (recv) {
+        in.n_classes = (int64_t)words[8]; in.n_ids = (int64_t)words[9];
+        in.unaligned = (int64_t)words[10]; in.units = (int64_t)words[11]; in.first_seen_bound = (int64_t)words[12];
+        if (in.n_classes < 0 || in.n_ids < 0 || in.n_classes >= (1LL << 40) || in.n_ids >= (1LL << 40))
+            return fail(SKM_ERR_COMM, "received a table header that makes no sense");
+        SKM_TRY(start.ensure(std::max<int64_t>(in.n_classes, 1))); SKM_TRY(len.ensure(std::max<int64_t>(in.n_classes, 1)));
+        SKM_TRY(count.ensure(std::max<int64_t>(in.n_classes, 1))); SKM_TRY(first_seen.ensure(std::max<int64_t>(in.n_classes, 1)));
+        SKM_TRY(ids.ensure(std::max<int64_t>(in.n_ids, 1))); SKM_TRY(fld.ensure(MAX_FRAGMENT_LENGTH));
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    if (send) {
+        if (out.n_classes) {
+            NCCL_TRY(g_rccl.Send(out.class_start, (size_t)out.n_classes, NCCL_UINT64, send_to, comm->comm, stream));
+            NCCL_TRY(g_rccl.Send(out.class_len, (size_t)out.n_classes, NCCL_UINT64, send_to, comm->comm, stream));
+            NCCL_TRY(g_rccl.Send(out.class_count, (size_t)out.n_classes, NCCL_FLOAT64, send_to, comm->comm, stream));
+            NCCL_TRY(g_rccl.Send(out.first_seen, (size_t)out.n_classes, NCCL_UINT64, send_to, comm->comm, stream));
+        }
+        if (out.n_ids) NCCL_TRY(g_rccl.Send(out.ids, (size_t)out.n_ids, NCCL_INT32, send_to, comm->comm, stream));
+        NCCL_TRY(g_rccl.Send(out.fld, MAX_FRAGMENT_LENGTH, NCCL_UINT64, send_to, comm->comm, stream));
+    }
+    if (recv) {
+        if (in.n_classes) {
+            NCCL_TRY(g_rccl.Recv(start.p, (size_t)in.n_classes, NCCL_UINT64, recv_from, comm->comm, stream));
+            NCCL_TRY(g_rccl.Recv(len.p, (size_t)in.n_classes, NCCL_UINT64, recv_from, comm->comm, stream));
+            NCCL_TRY(g_rccl.Recv(count.p, (size_t)in.n_classes, NCCL_FLOAT64, recv_from, comm->comm, stream));
+            NCCL_TRY(g_rccl.Recv(first_seen.p, (size_t)in.n_classes, NCCL_UINT64, recv_from, comm->comm, stream));
+        }
+        if (in.n_ids) NCCL_TRY(g_rccl.Recv(ids.p, (size_t)in.n_ids, NCCL_INT32, recv_from, comm->comm, stream));
+        NCCL_TRY(g_rccl.Recv(fld.p, MAX_FRAGMENT_LENGTH, NCCL_UINT64, recv_from, comm->comm, stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (!recv) return SKM_OK;
+    in.class_start = start.p; in.class_len = len.p; in.class_count = count.p;
+    in.first_seen = (const uint64_t *)first_seen.p; in.ids = ids.p; in.fld = (const uint64_t *)fld.p;
+    return skm_mapper_merge_device(recv, &in);
 }
 
 extern "C" int skm_comm_destroy(skm_comm *c)

@@ -1554,3 +1554,16 @@ def test_tables_merge_on_the_device(oracle, native_libs, chr21, chr21_oracle_ind
     for got, want in zip(by_host[0].export(), reference):
         np.testing.assert_array_equal(got, want)
 
+
+
+def test_table_hand_over_through_rccl(native_libs):
+    """skm_mapper_exchange_tables: a mapper's table sent as it lies in HBM (ncclSend / ncclRecv) and
+    merged by key on the receiving side -- on one GPU a rank sends to itself, which drives the
+    whole data path (header, six arrays, merge kernel): the receiving mapper then holds the table of
+    the whole sample, first-seen order included (scripts/micro/exchange_self.py asserts it).  In a
+    process of its own and under a time limit: an unmatched send would wait for ever."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts', 'micro', 'exchange_self.py')
+    done = subprocess.run([sys.executable, script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    assert done.returncode == 0 and b'exchange ok' in done.stdout, done.stdout.decode()[-2000:]
