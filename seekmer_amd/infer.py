@@ -82,7 +82,7 @@ def _run(ranks, start_time, index_path, output_path, fastq_paths, job_count, sav
     comm = parallel.make_comm(ranks, device)
     try:
         summarized_results, main_result = finish(map_result, ranks,
-                                                 lambda result: quantify_resident(result, comm=comm))
+                                                 lambda result: quantify_resident(result, comm=comm), comm=comm)
     finally:
         parallel.destroy_comm(comm)
     if ranks.rank == 0:
@@ -144,12 +144,16 @@ def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches):
                                    threads=parse_threads, pinned=total > (4 << 30), shard=shard)
 
 
-def finish(map_result, ranks, quantify_ranks):
+def finish(map_result, ranks, quantify_ranks, comm=None):
     """From the ranks' tables to the sample's results.  One rank: summarize + quantify as the
     reference does (seekmer/infer.py:66-78).  Several: `quantify_ranks(map_result)` runs the EM
     over the rank-local tables (collectives inside; every rank gets the TPM of the whole sample),
     THEN the other ranks' tables go to rank 0 and are merged into its own, whose summary is the
-    whole sample's: (SummarizedResult, TPM) on rank 0, (None, TPM) elsewhere."""
+    whole sample's: (SummarizedResult, TPM) on rank 0, (None, TPM) elsewhere.  The tables travel as
+    numpy arrays through the process group (host copy, rank 0 merges on its GPU) -- or, with
+    SKM_HANDOVER=rccl and a communicator, from GPU to GPU as they lie in HBM
+    (parallel.hand_over_device: ncclSend / ncclRecv + merge by key; experimental, no multi-GPU
+    node has run it yet)."""
     from . import parallel
     if ranks.world == 1:
         summarized = map_result.summarize()
@@ -157,6 +161,10 @@ def finish(map_result, ranks, quantify_ranks):
         return summarized, quantify(summarized)
     _LOG.info('Quantifying transcripts')
     tpm = quantify_ranks(map_result)
+    import os
+    if comm and os.environ.get('SKM_HANDOVER') == 'rccl':
+        parallel.hand_over_device(map_result, comm, ranks)
+        return (map_result.summarize() if ranks.rank == 0 else None), tpm
     tables = ranks.gather_arrays_to_root(parallel.rank_table(map_result) if ranks.rank else {})
     if ranks.rank != 0:
         return None, tpm

@@ -215,6 +215,19 @@ def merge_into(map_result, tables):
                                int(numpy.asarray(table['unaligned']).reshape(-1)[0]), table['fld'])
 
 
+def hand_over_device(map_result, comm, ranks):
+    """The ranks' tables to rank 0 from GPU to GPU (skm_mapper_exchange_tables): rank r sends its table
+    as it lies in HBM, rank 0 receives the others' one after the other and merges each by key on its
+    GPU.  Every rank calls this; the order of the calls pairs every send with its receive."""
+    from . import _native
+    hip = _native.hip()
+    if ranks.rank == 0:
+        for peer in range(1, ranks.world):
+            _native.check(hip.skm_mapper_exchange_tables(None, -1, map_result._handle, peer, comm))
+    else:
+        _native.check(hip.skm_mapper_exchange_tables(map_result._handle, 0, None, -1, comm))
+
+
 def shared_index(build, rank, world, barrier=None, cache=None):
     """One index for all ranks of a node: rank 0 builds it (or finds it in `cache`) and saves the
     container, the others wait at `barrier` and map the same file (KMerIndex.load memory-maps
