@@ -242,7 +242,7 @@ struct skm_quant {
     DBuf<int32_t> ids, tx_cls, row_tx, perm;      // perm[k] = caller's index of internal class k
     DBuf<double> cls_count, cls_count_saved, inner, row_sum;
     DBuf<double> eff_len, x0, x1, acc, part_max;
-    DBuf<unsigned int> part_flags;
+    DBuf<unsigned int> part_flags, arrivals;
     DBuf<unsigned long long> ctl, cum;
     DBuf<unsigned int> tile_total;            // scratch of the tiled multinomial draw
     DBuf<double> x_start, boot_out;           // bootstrap: the common start vector, the replicates' results
@@ -2062,6 +2062,8 @@ int quant_alloc(skm_quant *q, int device, int64_t n_tx, int64_t n_classes, int64
     SKM_TRY(q->ctl.ensure(16));
     SKM_TRY(q->part_max.ensure(EM_FINAL_BLOCKS));
     SKM_TRY(q->part_flags.ensure(EM_FINAL_BLOCKS));
+    SKM_TRY(q->arrivals.ensure(T));
+    HIP_TRY(hipMemsetAsync(q->arrivals.p, 0, T * sizeof(unsigned int), q->stream));
     STALE_CHECK("quant_alloc exit");
     return SKM_OK;
 }
@@ -2173,6 +2175,9 @@ EmProblem em_problem(skm_quant *q, double rel_tol, double x_floor, int64_t max_i
     p.part_flags = q->part_flags.p;
     p.max_iters = max_iters;
     p.fixed_iters = fixed_iters;
+    static const bool unfused = getenv("SKM_EM_UNFUSED") != nullptr;     // tuning aid: rows and finalize as two launches
+    p.fused = q->comm || unfused ? 0 : 1;      // (several ranks: the all-reduce sits between rows and finalize)
+    p.arrivals = q->arrivals.p;
     return p;
 }
 
@@ -2202,14 +2207,19 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
         for (int64_t i = 0; i < chunk; ++i, ++k) {
             // (the first step of a chunk follows the chunk-end em_decide: already judged)
             launch_em_inner(p, (int)(k & 1), i > 0, k, q->stream);
-            launch_em_rows(p, (int)(k & 1), q->stream);
             if (q->comm) {
+                launch_em_rows(p, (int)(k & 1), q->stream);
                 launch_em_rows_to_acc(p, q->stream);
                 NCCL_TRY(g_rccl.AllReduce(q->acc.p, q->acc.p, (size_t)q->n_tx, NCCL_FLOAT64, NCCL_SUM,
                                           q->comm, q->stream));
+                launch_em_finalize(p, (int)(k & 1), true, q->stream);
+            } else if (p.fused) {
+                launch_em_rows_finalize(p, (int)(k & 1), q->stream);     // (rows + finalize: one launch)
+            } else {
+                launch_em_rows(p, (int)(k & 1), q->stream);
+                launch_em_finalize(p, (int)(k & 1), false, q->stream);
             }
-            launch_em_finalize(p, (int)(k & 1), q->comm != nullptr, q->stream);
-            q->launches += q->comm ? 4 : 3;
+            q->launches += q->comm ? 4 : (p.fused ? 2 : 3);
         }
         launch_em_decide(p, k, q->stream);
         q->launches += 1;
@@ -2451,7 +2461,7 @@ extern "C" int skm_quant_destroy(skm_quant *q)
     q->cls_offset.release(); q->row_start.release(); q->tx_row.release(); q->ids.release();
     q->tx_cls.release(); q->row_tx.release(); q->perm.release(); q->cls_count.release(); q->cls_count_saved.release();
     q->inner.release(); q->row_sum.release(); q->eff_len.release(); q->x0.release(); q->x1.release();
-    q->acc.release(); q->part_max.release(); q->part_flags.release(); q->ctl.release();
+    q->acc.release(); q->part_max.release(); q->part_flags.release(); q->arrivals.release(); q->ctl.release();
     q->cum.release(); q->tile_total.release(); q->x_start.release(); q->boot_out.release();
     q->batch.cls_count.release(); q->batch.inner.release(); q->batch.row_sum.release(); q->batch.x0.release();
     q->batch.x1.release(); q->batch.part_max.release(); q->batch.part_flags.release(); q->batch.ctl.release();

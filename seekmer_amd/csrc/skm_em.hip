@@ -99,6 +99,89 @@ em_rows_kernel(EmProblem p, int parity)
     }
 }
 
+// em_rows and em_finalize in ONE launch (one rank: nothing to all-reduce between them).  Every
+// transcript has at least one row (skm_quant_setup.hip), nearly every transcript exactly one: the
+// 8-lane group that has summed such a row finalizes its transcript on the spot -- x'_t, NaN -> 0,
+// the relative change -- with the arithmetic of em_finalize_kernel (a = 0.0 + row sum), and the
+// block's partials of the stopping rule come out of this kernel.  The rows of a transcript that
+// sits in more than EM_ROW_CAP classes may be summed by different blocks; the group whose row
+// arrives LAST adds them up in row order and finalizes: row sums cross blocks as 8-byte
+// agent-scope atomic stores and loads (write-through / L2-bypassing: the XCDs' L2s are not
+// coherent), the store completed (s_waitcnt) before the arrival is counted.  One launch (5.1 us)
+// and one launch gap less per step; bit for bit em_rows + em_finalize.
+__global__ void __launch_bounds__(256)
+em_rows_finalize_kernel(EmProblem p, int parity)
+{
+    if (p.ctl[CTL_DONE]) return;
+    __shared__ double s_max[4];
+    __shared__ unsigned int s_flags[4];
+    const double *__restrict__ x = p.x[parity];
+    double *__restrict__ x_new = p.x[parity ^ 1];
+    const int sub = threadIdx.x & 7;
+    double local_max = 0.0;
+    unsigned int flags = 0;
+    for (int64_t r = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; r < p.n_rows;
+         r += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int64_t begin = p.row_start[r], end = p.row_start[r + 1];
+        const int32_t t = p.row_tx[r];
+        const double xt = x[t];
+        // (what the finalize needs is asked for with x[t]: one round trip for all of it)
+        const int64_t first_row = p.tx_row[t], rows_of_t = p.tx_row[t + 1] - first_row;
+        const double eff = p.eff_len[t];
+        double s = 0.0;
+        int64_t e = begin + sub;
+        for (; e + 8 < end; e += 16) {          // two independent gathers in flight per lane
+            const int32_t c0 = p.tx_cls[e], c1 = p.tx_cls[e + 8];
+            const double i0 = p.inner[c0], i1 = p.inner[c1];
+            s += xt / i0;
+            s += xt / i1;
+        }
+        for (; e < end; e += 8) s += xt / p.inner[p.tx_cls[e]];
+        s += __shfl_xor(s, 4, 8);
+        s += __shfl_xor(s, 2, 8);
+        s += __shfl_xor(s, 1, 8);
+        if (sub != 0) continue;
+        double a = 0.0;
+        if (rows_of_t == 1) {
+            a += s;
+        } else {
+            unsigned long long *const sums = reinterpret_cast<unsigned long long *>(p.row_sum);
+            __hip_atomic_store(&sums[r], (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int before = atomicAdd(&p.arrivals[t], 1u);
+            if ((int64_t)before + 1 != rows_of_t) continue;            // another row of this transcript is still to come
+            for (int64_t k = 0; k < rows_of_t; ++k)
+                a += __longlong_as_double((long long)__hip_atomic_load(&sums[first_row + k], __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT));
+            atomicExch(&p.arrivals[t], 0u);                           // (for the next step)
+        }
+        double v = a / eff / p.n_total;                               // infer.py:158
+        if (v != v) v = 0.0;                                          // infer.py:159
+        x_new[t] = v;
+        if (v > p.x_floor) {                                          // infer.py:160
+            const double change = fabs(v - xt) / v;
+            if (change != change) flags |= 2u;
+            else if (change > local_max) local_max = change;
+            flags |= 1u;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const double o = __shfl_xor(local_max, d, 64);
+        local_max = o > local_max ? o : local_max;
+        flags |= __shfl_xor(flags, d, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_max[wave] = local_max; s_flags[wave] = flags; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_max[0];
+        unsigned int f = s_flags[0];
+        for (int w = 1; w < 4; ++w) { m = s_max[w] > m ? s_max[w] : m; f |= s_flags[w]; }
+        p.part_max[blockIdx.x] = m;             // judged by em_evaluate in the next launch
+        p.part_flags[blockIdx.x] = f;
+    }
+}
+
 // multi-GPU only: rows -> per-transcript numerators for the all-reduce
 __global__ void __launch_bounds__(256)
 em_rows_to_acc_kernel(EmProblem p)
@@ -506,9 +589,11 @@ static inline unsigned chip_grid(int64_t work_items, int items_per_block)
     return (unsigned)blocks;
 }
 
+// blocks of the launch that writes the stopping rule's partials = partials the judge reads:
+// em_finalize's (several ranks) or em_rows_finalize's (p.fused)
 int em_final_blocks(const EmProblem &p)
 {
-    int64_t blocks = (p.n_tx + 255) / 256;
+    int64_t blocks = p.fused ? (p.n_rows + 31) / 32 : (p.n_tx + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
     return (int)blocks;
@@ -528,6 +613,11 @@ void launch_em_decide(const EmProblem &p, int64_t steps_done, hipStream_t stream
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream)
 {
     hipLaunchKernelGGL(em_rows_kernel, dim3(chip_grid(p.n_rows, 32)), dim3(256), 0, stream, p, parity);
+}
+
+void launch_em_rows_finalize(const EmProblem &p, int parity, hipStream_t stream)
+{
+    hipLaunchKernelGGL(em_rows_finalize_kernel, dim3((unsigned)em_final_blocks(p)), dim3(256), 0, stream, p, parity);
 }
 
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream)

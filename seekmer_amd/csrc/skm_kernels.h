@@ -158,12 +158,20 @@ struct EmProblem {
     double *part_max;             // [EM_FINAL_BLOCKS]
     unsigned int *part_flags;     // [EM_FINAL_BLOCKS] bit0 = any, bit1 = nan
     int64_t max_iters, fixed_iters;
+    // one rank: rows and finalize are ONE launch (em_rows_finalize_kernel); `arrivals` [T] counts the
+    // rows of a many-row transcript that have been summed in the current step (zero between steps)
+    int fused;
+    unsigned int *arrivals;
 };
-constexpr int EM_FINAL_BLOCKS = 1024;
+#ifndef SKM_EM_FINAL_BLOCKS
+#define SKM_EM_FINAL_BLOCKS 2048
+#endif
+constexpr int EM_FINAL_BLOCKS = SKM_EM_FINAL_BLOCKS;
 // judge_previous: apply the stopping rule to finalize pass `steps_done` first (see em_evaluate)
 void launch_em_inner(const EmProblem &p, int parity, bool judge_previous, int64_t steps_done, hipStream_t stream);
 void launch_em_decide(const EmProblem &p, int64_t steps_done, hipStream_t stream);
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream);
+void launch_em_rows_finalize(const EmProblem &p, int parity, hipStream_t stream);
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream);
 void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream);
 // out = the result of an EM that latched after ctl[1] steps (x0 if even, x1 if odd)

@@ -210,8 +210,10 @@ row_count_kernel(const int64_t *tx_offset, int64_t n_tx, int64_t *rows)
 {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_tx;
          t += (int64_t)gridDim.x * blockDim.x) {
+        // (at least one row, an empty one for a transcript no class names: the launch that sums the
+        // rows is also the one that finalizes the transcripts, skm_em.hip: em_rows_finalize_kernel)
         const int64_t degree = tx_offset[t + 1] - tx_offset[t];
-        rows[t] = (degree + EM_ROW_CAP - 1) / EM_ROW_CAP;
+        rows[t] = degree > 0 ? (degree + EM_ROW_CAP - 1) / EM_ROW_CAP : 1;
     }
 }
 
