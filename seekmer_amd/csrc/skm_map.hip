@@ -913,19 +913,6 @@ map_units_kernel(DevIndex ix, MapBatch b)
             };
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
 
-            if (valid && action == A_MERGE) {
-                // ---------------------------------- the one _filter_on_contig site
-                const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
-                if (state == M_LJ) {
-                    if (ok) state = N_LEFT;
-                    else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
-                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
-                } else if (state == M_LS) {
-                    if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
-                } else {
-                    if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
-                }
-            }
             if (valid && action == A_START) {
                 rv = read_view(block_records, b.record_words, b.words_per_read, first_read + (uint32_t)mate);
                 attempt = 0;
@@ -1064,6 +1051,18 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     } else {
                         state = N_MATE_DONE;
                     }
+                }
+            } else if (valid && action == A_MERGE) {
+                // ---------------------------------- the one _filter_on_contig site
+                const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
+                if (state == M_LJ) {
+                    if (ok) state = N_LEFT;
+                    else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
+                } else if (state == M_LS) {
+                    if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
+                } else {
+                    if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
                 }
             } else if (valid && action == A_LEFT) {
                 // --------------- _filter_targets_to_left: loop head + alignment step

@@ -64,3 +64,23 @@ def test_product_never_imports_the_oracle():
                 assert 'skmo_' not in text, name
                 assert 'import oracle' not in text and 'from oracle' not in text, name
                 assert 'libskm_oracle' not in text, name
+
+
+def test_the_production_map_kernel_does_not_spill(native_libs):
+    """map_units_kernel<false, true> runs at 128 VGPRs (4 waves per SIMD) WITHOUT scratch: 7 spilled registers were
+    3 GB of HBM writes per 10 M pairs in the counters of round 4 (WRITE_SIZE x 7), caused by moving one branch of the
+    action switch.  The build keeps the compiler's resource remarks beside the object."""
+    import re
+    import subprocess
+    remarks = os.path.join(ROOT, 'seekmer_amd', 'csrc', 'build', 'skm_map.remarks')
+    if not os.path.exists(remarks):
+        subprocess.check_call(['touch', os.path.join(ROOT, 'seekmer_amd', 'csrc', 'skm_map.hip')])
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'seekmer_amd', 'csrc')], stdout=subprocess.DEVNULL)
+    text = open(remarks).read()
+    blocks = text.split('Function Name: ')
+    mine = [b for b in blocks if b.startswith('_ZN3skm16map_units_kernelILb0ELb1EEE')]
+    assert len(mine) == 1
+    scratch = int(re.search(r'ScratchSize \[bytes/lane\]: (\d+)', mine[0]).group(1))
+    vgprs = int(re.search(r' VGPRs: (\d+)', mine[0]).group(1))
+    spilled = int(re.search(r'VGPRs Spill: (\d+)', mine[0]).group(1))
+    assert scratch == 0 and spilled == 0 and vgprs <= 128, (scratch, spilled, vgprs)
