@@ -2425,6 +2425,8 @@ extern "C" int skm_quant_infer(skm_mapper *m, skm_comm *comm, const double *leng
         lap("start vector");
         SKM_TRY(quant_finish_setup(q, &m->t, m->first_seen_bound));
         lap("setup");
+        if (trace) fprintf(stderr, "[skm_quant_infer] %lld classes, %lld transcripts, %lld rows\n", (long long)C, (long long)n_tx,
+                           (long long)q->n_rows);
         int64_t it = 0;
         SKM_TRY(em_run(q, rel_tol, x_floor, max_iters, 0, &it));
         lap("em");

@@ -140,21 +140,41 @@ em_rows_finalize_kernel(EmProblem p, int parity)
         s += __shfl_xor(s, 4, 8);
         s += __shfl_xor(s, 2, 8);
         s += __shfl_xor(s, 1, 8);
-        if (sub != 0) continue;
+        // 1: the transcript's only row; 2: the last of its rows to arrive (this group adds them up); 0: neither
+        int mode = 0;
+        unsigned long long *const sums = reinterpret_cast<unsigned long long *>(p.row_sum);
+        if (sub == 0) {
+            if (rows_of_t == 1) {
+                mode = 1;
+            } else {
+                __hip_atomic_store(&sums[r], (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int before = atomicAdd(&p.arrivals[t], 1u);
+                mode = (int64_t)before + 1 == rows_of_t ? 2 : 0;
+            }
+        }
+        mode = __shfl(mode, 0, 8);
+        if (mode == 0) continue;
         double a = 0.0;
-        if (rows_of_t == 1) {
+        if (mode == 1) {
             a += s;
         } else {
-            unsigned long long *const sums = reinterpret_cast<unsigned long long *>(p.row_sum);
-            __hip_atomic_store(&sums[r], (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned int before = atomicAdd(&p.arrivals[t], 1u);
-            if ((int64_t)before + 1 != rows_of_t) continue;            // another row of this transcript is still to come
-            for (int64_t k = 0; k < rows_of_t; ++k)
-                a += __longlong_as_double((long long)__hip_atomic_load(&sums[first_row + k], __ATOMIC_RELAXED,
-                                                                       __HIP_MEMORY_SCOPE_AGENT));
-            atomicExch(&p.arrivals[t], 0u);                           // (for the next step)
+            // (the eight lanes fetch eight row sums at a time; they are added in row order, as
+            // em_finalize_kernel adds them: a transcript in 100 000 classes has 200 rows)
+            for (int64_t k0 = 0; k0 < rows_of_t; k0 += 8) {
+                const int64_t k = k0 + sub;
+                const double mine = k < rows_of_t
+                    ? __longlong_as_double((long long)__hip_atomic_load(&sums[first_row + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double v = __shfl(mine, j, 8);
+                    if (k0 + j < rows_of_t) a += v;
+                }
+            }
+            if (sub == 0) atomicExch(&p.arrivals[t], 0u);             // (for the next step)
         }
+        if (sub != 0) continue;
         double v = a / eff / p.n_total;                               // infer.py:158
         if (v != v) v = 0.0;                                          // infer.py:159
         x_new[t] = v;

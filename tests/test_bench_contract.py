@@ -22,8 +22,8 @@ def _line(name):
     return json.load(open(path))
 
 
-@pytest.mark.parametrize('name, config', [('r03_bench.json', 1), ('r02_bench.json', 1), ('r02_bench_config3.json', 3),
-                                          ('r02_bench_config4.json', 4)])
+@pytest.mark.parametrize('name, config', [('r04_bench.json', 1), ('r03_bench.json', 1), ('r02_bench.json', 1),
+                                          ('r02_bench_config3.json', 3), ('r02_bench_config4.json', 4)])
 def test_committed_bench_lines_follow_the_contract(name, config):
     line = _line(name)
     baseline = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
@@ -91,3 +91,29 @@ def test_default_line_times_the_other_single_gpu_configs():
     assert third['value'] == pytest.approx(50_000_000 / (third['ms_per_step'] * 1e-3), rel=1e-6)
     assert fourth['unit'] == 'pairs/s' and fourth['bootstraps'] == 100 and fourth['bootstraps_per_s'] > 0
     assert fourth['value'] == pytest.approx(20_000_000 / (fourth['ms_per_step'] * 1e-3), rel=1e-6)
+
+
+def test_round4_line_checks_its_own_parity_and_times_the_north_star_size():
+    """profiles/r04_bench.json: the default run compares the counting build's table with the production launch's at every
+    benched size and the oracle's table with the HIP path's on the cpu_baseline sample (a mismatch fails the run), times
+    BASELINE.json north_star's 50 M 2x100 pairs on one GPU, and reports what one cold process sees from FASTQ text."""
+    line = _line('r04_bench.json')
+    parity = line['parity_checked']
+    assert parity['counting_vs_production']['identical'] is True and parity['counting_vs_production']['units'] == 10_000_000
+    sample = parity['cpu_sample_vs_hip']
+    assert sample['tables_identical'] is True and sample['units'] >= 1_000_000 and sample['tpm_max_rel_diff'] < 1e-4
+    others = line['other_configs']
+    assert sorted(others) == ['configs[3]', 'configs[4]', 'north_star: 50 M 2x100 pairs']
+    for sub in others.values():
+        assert sub['parity_checked']['counting_vs_production']['identical'] is True
+    star = others['north_star: 50 M 2x100 pairs']
+    assert star['unit'] == 'pairs/s' and '50000000 2x100bp' in star['workload'] and star['steps'] >= 2
+    assert star['value'] == pytest.approx(50_000_000 / (star['ms_per_step'] * 1e-3), rel=1e-6)
+    assert star['parity_checked']['counting_vs_production']['units'] == 50_000_000
+    roofline = line['roofline']
+    assert roofline['traffic'] is not None and 'r04_pmc_map.json' in roofline['traffic_source']
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_map.json')))
+    assert roofline['traffic'] == pmc['derived']['hbm_traffic_bytes'] and len(pmc['source_hash']) == 16
+    cold = line['e2e']['fastq_inclusive']['cold_process']
+    assert cold['unit'] == 'pairs/s' and cold['without_prefault']['value'] <= cold['value'] < line['e2e']['fastq_inclusive']['parse_only']
+    assert line['e2e']['fastq_inclusive']['first_pass'] <= line['e2e']['fastq_inclusive']['value']
