@@ -2654,6 +2654,8 @@ int bootstrap_impl(skm_quant *q, int64_t n_boot, uint64_t seed, const double *x0
     p.managed = 1;
     p.mgr = w.mgr.p;
     p.iters_out = w.iters.p;
+    p.fused = getenv("SKM_EM_UNFUSED") ? 0 : 1;
+    p.arrivals = q->arrivals.p;
     int64_t chunk = 16;                                          // steps queued between two looks at the progress
     if (const char *e = getenv("SKM_BOOTSTRAP_CHUNK")) chunk = std::max<int64_t>(1, atoll(e));   // (tests)
     unsigned long long *const look = q->pinned + 64;             // 64 + 8 words of the pinned block

@@ -109,7 +109,7 @@ em_rows_kernel(EmProblem p, int parity)
 // agent-scope atomic stores and loads (write-through / L2-bypassing: the XCDs' L2s are not
 // coherent), the store completed (s_waitcnt) before the arrival is counted.  One launch (5.1 us)
 // and one launch gap less per step; bit for bit em_rows + em_finalize.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)       // (8 waves per SIMD: the 2048-block grid is resident at once)
 em_rows_finalize_kernel(EmProblem p, int parity)
 {
     if (p.ctl[CTL_DONE]) return;

@@ -246,6 +246,99 @@ em_finalize_batch_kernel(EmBatchProblem p, int parity)
     }
 }
 
+// em_rows_batch and em_finalize_batch in ONE launch (skm_em.hip: em_rows_finalize_kernel is the
+// single-problem form).  After the row's eight partial sums have been combined every lane of the
+// 8-lane group holds all eight replicates' row sums; lane r finalizes replicate r of the row's
+// transcript -- all eight lanes busy, with em_finalize_batch_kernel's arithmetic (a = 0.0 + row sum)
+// -- when the transcript has this one row (every transcript of the benchmarked tables has), and for a
+// transcript of several rows the group whose row arrives last adds them up in row order (row sums
+// cross blocks as agent-scope atomic stores / loads, the store completed before the arrival counts).
+__global__ void __launch_bounds__(256)
+em_rows_finalize_batch_kernel(EmBatchProblem p, int parity)
+{
+    if (p.ctl[BCTL_ALL_DONE]) return;
+    __shared__ double s_max[4][R];
+    __shared__ unsigned int s_flags[4][R];
+    const double *__restrict__ x = p.x[parity];
+    double *__restrict__ x_new = p.x[parity ^ 1];
+    const int sub = threadIdx.x & 7;
+    const bool stopped = p.ctl[BCTL_DONE + sub] != 0;          // this lane's replicate (r = sub) is frozen
+    double local_max = 0.0;
+    unsigned int flags = 0;
+    for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; row < p.n_rows;
+         row += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+        const int64_t begin = p.row_start[row], end = p.row_start[row + 1];
+        const int32_t t = p.row_tx[row];
+        const double *__restrict__ xt = x + (int64_t)t * R;
+        const int64_t first_row = p.tx_row[t], rows_of_t = p.tx_row[t + 1] - first_row;
+        const double eff = p.eff_len[t];
+        double xr[R], s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { xr[r] = xt[r]; s[r] = 0.0; }
+        for (int64_t e = begin + sub; e < end; e += 8) {
+            const double *__restrict__ inner = p.inner + (int64_t)p.tx_cls[e] * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] += xr[r] / inner[r];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s[r] += __shfl_xor(s[r], 4, 8);
+            s[r] += __shfl_xor(s[r], 2, 8);
+            s[r] += __shfl_xor(s[r], 1, 8);
+        }
+        double mine = s[0], before = xr[0];                    // replicate `sub` of this row
+#pragma unroll
+        for (int r = 1; r < R; ++r) { mine = sub == r ? s[r] : mine; before = sub == r ? xr[r] : before; }
+        double a = 0.0;
+        if (rows_of_t == 1) {
+            a += mine;
+        } else {
+            unsigned long long *const sums = reinterpret_cast<unsigned long long *>(p.row_sum);
+            __hip_atomic_store(&sums[row * R + sub], (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the eight stores of the group are complete: the wait above is per wave, and the group is in one)
+            unsigned int arrived = 0;
+            if (sub == 0) arrived = atomicAdd(&p.arrivals[t], 1u) + 1u;
+            arrived = __shfl(arrived, 0, 8);
+            if ((int64_t)arrived != rows_of_t) continue;          // another row of this transcript is still to come
+            for (int64_t k = 0; k < rows_of_t; ++k)
+                a += __longlong_as_double((long long)__hip_atomic_load(&sums[(first_row + k) * R + sub], __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT));
+            if (sub == 0) atomicExch(&p.arrivals[t], 0u);         // (for the next step)
+        }
+        double v = a / eff / p.n_total;                           // infer.py:158
+        if (v != v) v = 0.0;                                      // infer.py:159
+        if (stopped) {
+            x_new[(int64_t)t * R + sub] = before;                 // a stopped replicate keeps its result
+        } else {
+            x_new[(int64_t)t * R + sub] = v;
+            if (v > p.x_floor) {                                  // infer.py:160
+                const double change = fabs(v - before) / v;
+                if (change != change) flags |= 2u;
+                else if (change > local_max) local_max = change;
+                flags |= 1u;
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    for (int d = 32; d >= R; d >>= 1) {                          // over the lanes of the wave that hold replicate `sub`
+        const double o = __shfl_xor(local_max, d, 64);
+        local_max = o > local_max ? o : local_max;
+        flags |= __shfl_xor(flags, d, 64);
+    }
+    if ((threadIdx.x & 63) < R) { s_max[wave][sub] = local_max; s_flags[wave][sub] = flags; }
+    __syncthreads();
+    if (threadIdx.x < R) {
+        double m = s_max[0][sub];
+        unsigned int f = s_flags[0][sub];
+        for (int w = 1; w < 4; ++w) { m = s_max[w][sub] > m ? s_max[w][sub] : m; f |= s_flags[w][sub]; }
+        if (stopped) { m = 0.0; f = 1u; }                        // (see em_finalize_batch_kernel)
+        p.part_max[blockIdx.x * R + sub] = m;
+        p.part_flags[blockIdx.x * R + sub] = f;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 em_decide_batch_kernel(EmBatchProblem p, int n_parts, int64_t steps_done)
 {
@@ -337,7 +430,8 @@ inline unsigned grid_of(int64_t items, int per_block, int64_t cap = 256 * 8)
 
 int em_batch_final_blocks(const EmBatchProblem &p)
 {
-    int64_t blocks = (p.n_tx * EM_BATCH + 255) / 256;        // (a lane per transcript and replicate)
+    // (fused: the blocks of em_rows_finalize_batch, 32 rows each; else a lane per transcript and replicate)
+    int64_t blocks = p.fused ? (p.n_rows + 31) / 32 : (p.n_tx * EM_BATCH + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > EM_FINAL_BLOCKS) blocks = EM_FINAL_BLOCKS;
     return (int)blocks;
@@ -348,6 +442,11 @@ void launch_em_batch_step(const EmBatchProblem &p, int64_t step, hipStream_t str
     const int parity = (int)(step & 1);
     hipLaunchKernelGGL(em_inner_batch_kernel, dim3(grid_of(p.n_classes, 256 / EM_BATCH)), dim3(256), 0, stream, p, parity,
                        step > 0 ? em_batch_final_blocks(p) : 0, step);
+    if (p.fused) {
+        hipLaunchKernelGGL(em_rows_finalize_batch_kernel, dim3((unsigned)em_batch_final_blocks(p)), dim3(256), 0, stream, p,
+                           parity);
+        return;
+    }
     hipLaunchKernelGGL(em_rows_batch_kernel, dim3(grid_of(p.n_rows, 32)), dim3(256), 0, stream, p, parity);
     hipLaunchKernelGGL(em_finalize_batch_kernel, dim3((unsigned)em_batch_final_blocks(p)), dim3(256), 0, stream, p,
                        parity);

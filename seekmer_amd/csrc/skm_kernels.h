@@ -204,6 +204,8 @@ struct EmBatchProblem {
     int managed;                  // the device refills the places (launch_em_batch_manage): see skm_em_batch.hip
     unsigned long long *mgr;      // managed: the manager's words, planned for inside em_inner_batch (or nullptr)
     int64_t *iters_out;           // managed: step count of every replicate of the group
+    int fused;                    // rows and finalize are one launch (em_rows_finalize_batch_kernel)
+    unsigned int *arrivals;       // [T] rows of a many-row transcript summed so far in this step (zero between steps)
 };
 // The working set kept full by the device: `mgr` is 64 words of HBM; counts_all[i][C] the pre-drawn
 // class counts of replicate i of the group, out_all[i][T] its result, iters_out[i] its step count
