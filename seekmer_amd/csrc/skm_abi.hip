@@ -2828,10 +2828,20 @@ extern "C" int skm_mapper_exchange_tables(skm_mapper *send, int send_to, skm_map
                                     (unsigned long long)out.unaligned, (unsigned long long)out.units,
                                     (unsigned long long)out.first_seen_bound, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(header.p, words, 8 * 8, hipMemcpyHostToDevice, stream));
-    NCCL_TRY(g_rccl.GroupStart());
-    if (send) NCCL_TRY(g_rccl.Send(header.p, 8, NCCL_UINT64, send_to, comm->comm, stream));
-    if (recv) NCCL_TRY(g_rccl.Recv(header.p + 8, 8, NCCL_UINT64, recv_from, comm->comm, stream));
-    NCCL_TRY(g_rccl.GroupEnd());
+    // (a group that has been started is always ended, whatever a call inside it returned)
+    auto grouped = [&](const std::function<int()> &calls) -> int {
+        NCCL_TRY(g_rccl.GroupStart());
+        const int rc = calls();
+        const int end = g_rccl.GroupEnd();
+        if (rc != SKM_OK) return rc;
+        NCCL_TRY(end);
+        return SKM_OK;
+    };
+    SKM_TRY(grouped([&]() -> int {
+        if (send) NCCL_TRY(g_rccl.Send(header.p, 8, NCCL_UINT64, send_to, comm->comm, stream));
+        if (recv) NCCL_TRY(g_rccl.Recv(header.p + 8, 8, NCCL_UINT64, recv_from, comm->comm, stream));
+        return SKM_OK;
+    }));
     HIP_TRY(hipMemcpyAsync(words + 8, header.p + 8, 8 * 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     skm_device_table in{};
@@ -2845,7 +2855,7 @@ extern "C" int skm_mapper_exchange_tables(skm_mapper *send, int send_to, skm_map
         SKM_TRY(count.ensure(std::max<int64_t>(in.n_classes, 1))); SKM_TRY(first_seen.ensure(std::max<int64_t>(in.n_classes, 1)));
         SKM_TRY(ids.ensure(std::max<int64_t>(in.n_ids, 1))); SKM_TRY(fld.ensure(MAX_FRAGMENT_LENGTH));
     }
-    NCCL_TRY(g_rccl.GroupStart());
+    SKM_TRY(grouped([&]() -> int {
     if (send) {
         if (out.n_classes) {
             NCCL_TRY(g_rccl.Send(out.class_start, (size_t)out.n_classes, NCCL_UINT64, send_to, comm->comm, stream));
@@ -2866,7 +2876,8 @@ extern "C" int skm_mapper_exchange_tables(skm_mapper *send, int send_to, skm_map
         if (in.n_ids) NCCL_TRY(g_rccl.Recv(ids.p, (size_t)in.n_ids, NCCL_INT32, recv_from, comm->comm, stream));
         NCCL_TRY(g_rccl.Recv(fld.p, MAX_FRAGMENT_LENGTH, NCCL_UINT64, recv_from, comm->comm, stream));
     }
-    NCCL_TRY(g_rccl.GroupEnd());
+    return SKM_OK;
+    }));
     HIP_TRY(hipStreamSynchronize(stream));
     if (!recv) return SKM_OK;
     in.class_start = start.p; in.class_len = len.p; in.class_count = count.p;

@@ -14,8 +14,8 @@
 #include "skm_kernels.h"
 #include "skm_pool.h"
 
-#include <hipcub/hipcub.hpp>
-#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cstdio>
 #include <vector>
 
 namespace skm {
@@ -268,37 +268,249 @@ inline unsigned blocks_for(int64_t n)
     return (unsigned)b;
 }
 
-// exclusive scan of n int64 values into out[0..n) and the total into out[n] (all on the stream)
-int exclusive_scan_with_total(Scratch &scratch, const int64_t *in, int64_t *out, int64_t n)
+// ---- hand-written scan and stable radix sort (no library code on the path) -----------------------
+// Exclusive prefix sums of n values, three small launches: per-tile sums, one block over the tile
+// sums, per-tile scan with the tile's base.  SCAN_TILE values per block; the middle launch handles
+// any number of tiles (each of its 1024 lanes walks a run of them).
+constexpr int SCAN_TILE = 2048;               // 256 lanes x 8 values
+
+template <class T>
+__global__ void __launch_bounds__(256)
+scan_tile_sums_kernel(const T *__restrict__ in, int64_t n, T *__restrict__ tile_sums)
+{
+    __shared__ T s_wave[4];
+    const int64_t base = blockIdx.x * (int64_t)SCAN_TILE + threadIdx.x * 8;
+    T sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += base + k < n ? in[base + k] : (T)0;
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// tile_sums[i] <- sum of the tiles before i; *total (optional) <- the sum of all
+template <class T>
+__global__ void __launch_bounds__(1024)
+scan_of_sums_kernel(T *tile_sums, int64_t n_tiles, T *total)
+{
+    __shared__ T s_part[1024];
+    const int64_t per = (n_tiles + 1023) / 1024;
+    const int64_t first = threadIdx.x * per, last = min(n_tiles, first + per);
+    T sum = 0;
+    for (int64_t i = first; i < last; ++i) sum += tile_sums[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1) {
+        const T add = (int)threadIdx.x >= step ? s_part[threadIdx.x - step] : (T)0;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    T at = s_part[threadIdx.x] - sum;
+    for (int64_t i = first; i < last; ++i) { const T v = tile_sums[i]; tile_sums[i] = at; at += v; }
+    if (total && threadIdx.x == 1023) *total = s_part[1023];
+}
+
+template <class T>
+__global__ void __launch_bounds__(256)
+scan_tiles_kernel(const T *__restrict__ in, int64_t n, const T *__restrict__ tile_base, T *__restrict__ out)
+{
+    __shared__ T s_wave[4];
+    const int64_t base = blockIdx.x * (int64_t)SCAN_TILE + threadIdx.x * 8;
+    T v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? in[base + k] : (T)0; sum += v[k]; }
+    T incl = sum;                                  // inclusive scan of the lanes' sums over the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    T at = tile_base[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; ++w) at += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < n) out[base + k] = at;
+        at += v[k];
+    }
+}
+
+// out[0..n) = exclusive prefix sums of in, `total` (device, optional) = the sum; in == out allowed
+template <class T>
+int exclusive_scan(Scratch &scratch, const T *in, T *out, int64_t n, T *total)
 {
     hipStream_t stream = scratch.stream;
-    if (n == 0) {
-        QB_TRY(hipMemsetAsync(out, 0, sizeof(int64_t), stream));
+    if (n <= 0) {
+        if (total) QB_TRY(hipMemsetAsync(total, 0, sizeof(T), stream));
         return 0;
     }
-    size_t bytes = 0;
-    QB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, stream));
-    QB_ALLOC(tmp, char, bytes);
-    QB_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, stream));
-    hipLaunchKernelGGL(set_last_offset_kernel, dim3(1), dim3(64), 0, stream, out, in, n);
+    const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    QB_ALLOC(tile_sums, T, n_tiles);
+    hipLaunchKernelGGL(scan_tile_sums_kernel<T>, dim3((unsigned)n_tiles), dim3(256), 0, stream, in, n, tile_sums);
+    hipLaunchKernelGGL(scan_of_sums_kernel<T>, dim3(1), dim3(1024), 0, stream, tile_sums, n_tiles, total);
+    hipLaunchKernelGGL(scan_tiles_kernel<T>, dim3((unsigned)n_tiles), dim3(256), 0, stream, in, n, tile_sums, out);
     return 0;
 }
 
-// Stable radix sort of (key, value) pairs on bits [0, end_bit).  Onesweep at every size: below
-// 1 M items rocPRIM's default picks its merge sort, which at the 0.85 M classes of configs[1]
-// takes ten merge rounds (155 us) where three onesweep passes take a third of that.
-using OnesweepAlways = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                  rocprim::default_config, 0>;
+// exclusive scan of n int64 values into out[0..n) and the total into out[n] (all on the stream)
+int exclusive_scan_with_total(Scratch &scratch, const int64_t *in, int64_t *out, int64_t n)
+{
+    if (n >= (1LL << 40)) return -2;
+    return exclusive_scan<int64_t>(scratch, in, out, n, out + n);
+}
+
+// Stable least-significant-digit radix sort of (key, value) pairs on key bits [0, end_bit), 9 bits
+// (512 bins) per pass: the 18-bit keys of the class views take two passes.  A pass: a histogram per
+// tile of 4096 pairs (digit-major, so that ONE exclusive scan over it gives every (digit, tile) its
+// place), then the scatter -- a tile's four waves each own a quarter of it in order; a wave ranks 64
+// pairs at a time with nine ballots (the lanes that share my digit) against its running per-digit
+// base in LDS, the pairs are put in digit order in LDS and leave in runs.  Stable by construction:
+// tiles, waves, 64-pair chunks and lanes are all taken in input order within a digit.
+constexpr int RS_BITS = 9, RS_BINS = 1 << RS_BITS, RS_ITEMS = 16, RS_TILE = 256 * RS_ITEMS;
+
+template <class K>
+__global__ void __launch_bounds__(256)
+radix_hist_kernel(const K *__restrict__ keys, int64_t n, int shift, uint32_t *__restrict__ hist, int64_t n_tiles)
+{
+    __shared__ uint32_t h[RS_BINS];
+    for (int d = threadIdx.x; d < RS_BINS; d += 256) h[d] = 0;
+    __syncthreads();
+    const int64_t base = blockIdx.x * (int64_t)RS_TILE;
+#pragma unroll 4
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t at = base + i * 256 + threadIdx.x;
+        if (at < n) atomicAdd(&h[(uint32_t)((unsigned long long)keys[at] >> shift) & (RS_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < RS_BINS; d += 256) hist[d * n_tiles + blockIdx.x] = h[d];
+}
+
+template <class K>
+__global__ void __launch_bounds__(256)
+radix_scatter_kernel(const K *__restrict__ keys_in, const int32_t *__restrict__ vals_in, K *__restrict__ keys_out,
+                     int32_t *__restrict__ vals_out, int64_t n, int shift, const uint32_t *__restrict__ offsets,
+                     int64_t n_tiles)
+{
+    __shared__ uint32_t wave_base[4][RS_BINS];      // a wave's count per digit, then its running place in the tile
+    __shared__ uint32_t tile_start[RS_BINS + 1];    // where a digit's pairs start in the tile's digit order
+    __shared__ uint32_t s_scan[256];
+    __shared__ K s_keys[RS_TILE];
+    __shared__ int32_t s_vals[RS_TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = threadIdx.x; d < 4 * RS_BINS; d += 256) (&wave_base[0][0])[d] = 0;
+    __syncthreads();
+    // the wave's quarter of the tile, 64 consecutive pairs per chunk
+    const int64_t first = blockIdx.x * (int64_t)RS_TILE + wave * (RS_TILE / 4);
+    K key[RS_ITEMS];
+    int32_t val[RS_ITEMS];
+    uint32_t digit[RS_ITEMS];
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const int64_t at = first + c * 64 + lane;
+        const bool valid = at < n;
+        key[c] = valid ? keys_in[at] : (K)0;
+        val[c] = valid ? vals_in[at] : 0;
+        digit[c] = (uint32_t)((unsigned long long)key[c] >> shift) & (RS_BINS - 1);
+        if (valid) atomicAdd(&wave_base[wave][digit[c]], 1u);
+    }
+    __syncthreads();
+    // tile_start = exclusive scan over the digits of the tile's counts (two digits per lane)
+    const int d0 = 2 * threadIdx.x;
+    const uint32_t c0 = wave_base[0][d0] + wave_base[1][d0] + wave_base[2][d0] + wave_base[3][d0];
+    const uint32_t c1 = wave_base[0][d0 + 1] + wave_base[1][d0 + 1] + wave_base[2][d0 + 1] + wave_base[3][d0 + 1];
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    uint32_t at0 = incl - (c0 + c1);
+    for (int w = 0; w < wave; ++w) at0 += s_scan[w];
+    tile_start[d0] = at0;
+    tile_start[d0 + 1] = at0 + c0;
+    if (threadIdx.x == 255) tile_start[RS_BINS] = at0 + c0 + c1;
+    // a wave's running place for a digit: behind the earlier waves' pairs of that digit
+    uint32_t run0 = at0, run1 = at0 + c0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t n0 = wave_base[w][d0], n1 = wave_base[w][d0 + 1];
+        wave_base[w][d0] = run0; wave_base[w][d0 + 1] = run1;
+        run0 += n0; run1 += n1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const bool valid = first + c * 64 + lane < n;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RS_BITS; ++b) {
+            const bool bit = (digit[c] >> b) & 1u;
+            const unsigned long long with = __ballot(valid && bit);
+            same &= bit ? with : ~with;
+        }
+        if (valid) {
+            const uint32_t before = (uint32_t)__popcll(same & ((1ULL << lane) - 1ULL));
+            const uint32_t place = wave_base[wave][digit[c]] + before;
+            s_keys[place] = key[c];
+            s_vals[place] = val[c];
+            if (before == 0) wave_base[wave][digit[c]] += (uint32_t)__popcll(same);      // (the digit's first lane)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next chunk reads the bases this one moved
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    const int64_t tile_first = blockIdx.x * (int64_t)RS_TILE;
+    const uint32_t tile_n = (uint32_t)min((int64_t)RS_TILE, n - tile_first);
+#pragma unroll 4
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t j = i * 256 + threadIdx.x;
+        if (j >= tile_n) continue;
+        const K k = s_keys[j];
+        const uint32_t d = (uint32_t)((unsigned long long)k >> shift) & (RS_BINS - 1);
+        const int64_t to = (int64_t)offsets[d * n_tiles + blockIdx.x] + (j - tile_start[d]);
+        keys_out[to] = k;
+        vals_out[to] = s_vals[j];
+    }
+}
+
+// Stable radix sort of (key, value) pairs on bits [0, end_bit); the result lands in keys_out / vals_out.
 template <class K>
 int sort_pairs(Scratch &scratch, const K *keys_in, K *keys_out, const int32_t *vals_in, int32_t *vals_out,
                int64_t n, int end_bit)
 {
-    size_t bytes = 0;
-    QB_TRY(rocprim::radix_sort_pairs<OnesweepAlways>(nullptr, bytes, keys_in, keys_out, vals_in, vals_out,
-                                                     (size_t)n, 0u, (unsigned)end_bit, scratch.stream));
-    QB_ALLOC(tmp, char, bytes);
-    QB_TRY(rocprim::radix_sort_pairs<OnesweepAlways>(tmp, bytes, keys_in, keys_out, vals_in, vals_out,
-                                                     (size_t)n, 0u, (unsigned)end_bit, scratch.stream));
+    hipStream_t stream = scratch.stream;
+    if (n <= 0) return 0;
+    if (n >= (1LL << 32)) return -2;                                  // (offsets are 32-bit)
+    const int passes = std::max(1, (end_bit + RS_BITS - 1) / RS_BITS);
+    const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
+    QB_ALLOC(hist, uint32_t, RS_BINS * n_tiles);
+    K *tmp_keys = nullptr;
+    int32_t *tmp_vals = nullptr;
+    if (passes > 1) {
+        QB_ALLOC(tk, K, n); QB_ALLOC(tv, int32_t, n);
+        tmp_keys = tk; tmp_vals = tv;
+    }
+    const K *src_k = keys_in;
+    const int32_t *src_v = vals_in;
+    for (int pass = 0; pass < passes; ++pass) {
+        // (the last pass writes the caller's arrays; the passes before it alternate so that it can)
+        const bool to_out = ((passes - 1 - pass) & 1) == 0;
+        K *dst_k = to_out ? keys_out : tmp_keys;
+        int32_t *dst_v = to_out ? vals_out : tmp_vals;
+        const int shift = pass * RS_BITS;
+        hipLaunchKernelGGL(radix_hist_kernel<K>, dim3((unsigned)n_tiles), dim3(256), 0, stream, src_k, n, shift, hist, n_tiles);
+        if (exclusive_scan<uint32_t>(scratch, hist, hist, RS_BINS * n_tiles, (uint32_t *)nullptr)) return -1;
+        hipLaunchKernelGGL(radix_scatter_kernel<K>, dim3((unsigned)n_tiles), dim3(256), 0, stream, src_k, src_v, dst_k, dst_v, n,
+                           shift, hist, n_tiles);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
     return 0;
 }
 
