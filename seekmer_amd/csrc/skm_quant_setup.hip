@@ -148,7 +148,14 @@ copy_tuples_direct_kernel(int64_t n, const int64_t *src_off, const int32_t *aren
         const int64_t src = src_off[j];
         const int64_t dst = cls_offset[j];
         const int64_t len = cls_offset[j + 1] - dst;
-        for (int64_t i = 0; i < len; ++i) ids[dst + i] = arena[src + i];
+        // (eight ids in flight at a time: a tuple is 5.4 ids on average, somewhere in the arena)
+        for (int64_t i = 0; i < len; i += 8) {
+            int32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = i + k < len ? arena[src + i + k] : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (i + k < len) ids[dst + i + k] = v[k];
+        }
     }
 }
 
@@ -389,19 +396,73 @@ radix_hist_kernel(const K *__restrict__ keys, int64_t n, int shift, uint32_t *__
     for (int d = threadIdx.x; d < RS_BINS; d += 256) hist[d * n_tiles + blockIdx.x] = h[d];
 }
 
+// one block per digit: hist[d][0 .. n_tiles) <- its exclusive prefix sums, digit_total[d] <- its sum
+// (the scatter adds the digits before d: 512 totals, scanned by every block for itself)
+__global__ void __launch_bounds__(256)
+radix_digit_scan_kernel(uint32_t *hist, int64_t n_tiles, uint32_t *digit_total)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    uint32_t *row = hist + blockIdx.x * n_tiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 256 * 4) {
+        const int64_t at = base + threadIdx.x * 4;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = at + k < n_tiles ? row[at + k] : 0u; sum += v[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = s_carry + incl - sum;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (at + k < n_tiles) row[at + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = run;           // (the last lane's running sum = everything so far)
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = s_carry;
+}
+
 template <class K>
 __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const K *__restrict__ keys_in, const int32_t *__restrict__ vals_in, K *__restrict__ keys_out,
                      int32_t *__restrict__ vals_out, int64_t n, int shift, const uint32_t *__restrict__ offsets,
-                     int64_t n_tiles)
+                     const uint32_t *__restrict__ digit_total, int64_t n_tiles)
 {
     __shared__ uint32_t wave_base[4][RS_BINS];      // a wave's count per digit, then its running place in the tile
     __shared__ uint32_t tile_start[RS_BINS + 1];    // where a digit's pairs start in the tile's digit order
     __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t digit_base[RS_BINS];        // pairs of the whole input with a smaller digit
     __shared__ K s_keys[RS_TILE];
     __shared__ int32_t s_vals[RS_TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < 4 * RS_BINS; d += 256) (&wave_base[0][0])[d] = 0;
+    {   // digit_base = exclusive scan of the 512 digit totals (two digits per lane)
+        const uint32_t t0 = digit_total[2 * threadIdx.x], t1 = digit_total[2 * threadIdx.x + 1];
+        uint32_t incl = t0 + t1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        uint32_t at = incl - (t0 + t1);
+        for (int w = 0; w < wave; ++w) at += s_scan[w];
+        digit_base[2 * threadIdx.x] = at;
+        digit_base[2 * threadIdx.x + 1] = at + t0;
+    }
     __syncthreads();
     // the wave's quarter of the tile, 64 consecutive pairs per chunk
     const int64_t first = blockIdx.x * (int64_t)RS_TILE + wave * (RS_TILE / 4);
@@ -473,7 +534,7 @@ radix_scatter_kernel(const K *__restrict__ keys_in, const int32_t *__restrict__ 
         if (j >= tile_n) continue;
         const K k = s_keys[j];
         const uint32_t d = (uint32_t)((unsigned long long)k >> shift) & (RS_BINS - 1);
-        const int64_t to = (int64_t)offsets[d * n_tiles + blockIdx.x] + (j - tile_start[d]);
+        const int64_t to = (int64_t)digit_base[d] + offsets[d * n_tiles + blockIdx.x] + (j - tile_start[d]);
         keys_out[to] = k;
         vals_out[to] = s_vals[j];
     }
@@ -490,6 +551,7 @@ int sort_pairs(Scratch &scratch, const K *keys_in, K *keys_out, const int32_t *v
     const int passes = std::max(1, (end_bit + RS_BITS - 1) / RS_BITS);
     const int64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
     QB_ALLOC(hist, uint32_t, RS_BINS * n_tiles);
+    QB_ALLOC(digit_total, uint32_t, RS_BINS);
     K *tmp_keys = nullptr;
     int32_t *tmp_vals = nullptr;
     if (passes > 1) {
@@ -505,9 +567,9 @@ int sort_pairs(Scratch &scratch, const K *keys_in, K *keys_out, const int32_t *v
         int32_t *dst_v = to_out ? vals_out : tmp_vals;
         const int shift = pass * RS_BITS;
         hipLaunchKernelGGL(radix_hist_kernel<K>, dim3((unsigned)n_tiles), dim3(256), 0, stream, src_k, n, shift, hist, n_tiles);
-        if (exclusive_scan<uint32_t>(scratch, hist, hist, RS_BINS * n_tiles, (uint32_t *)nullptr)) return -1;
+        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(RS_BINS), dim3(256), 0, stream, hist, n_tiles, digit_total);
         hipLaunchKernelGGL(radix_scatter_kernel<K>, dim3((unsigned)n_tiles), dim3(256), 0, stream, src_k, src_v, dst_k, dst_v, n,
-                           shift, hist, n_tiles);
+                           shift, hist, digit_total, n_tiles);
         src_k = dst_k;
         src_v = dst_v;
     }
