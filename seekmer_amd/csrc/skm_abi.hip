@@ -814,9 +814,11 @@ int table_grow(skm_mapper *m, uint64_t want_slots, int64_t units_in_flight)
 // it once instead of growing step by step under the first runs of a sample.
 int table_reserve_for_sample(skm_mapper *m, int64_t sample_units)
 {
-    const double expect = (double)m->host_classes + (double)sample_units / 8.0 + 1024.0;
+    // (a hint, possibly a wild one: what it reserves is bounded -- 2^26 classes, 2 GB of table -- and
+    // a sample that needs more grows the table as before)
+    const double expect = (double)m->host_classes + (double)std::min<int64_t>(sample_units, 1LL << 29) / 8.0 + 1024.0;
     uint64_t want = 1 << 16;
-    while ((double)want * 0.5 < expect && want < (1ULL << 28)) want <<= 1;
+    while ((double)want * 0.5 < expect && want < (1ULL << 26)) want <<= 1;
     SKM_TRY(table_grow(m, want, 0));
     SKM_TRY(m->class_list.ensure((size_t)(expect + 1024.0), true, m->stream));
     SKM_TRY(m->arena.ensure((size_t)(m->host_arena_used + (int64_t)(expect * 6.0) + 1024), true, m->stream));
@@ -1629,10 +1631,14 @@ extern "C" int skm_mapper_map_packed_source(skm_mapper *m, skm_packed_source nex
     // paid every piece's copy time in full before (524 pieces x 25 us of a 42 ms pass).
     SKM_TRY(set_device(m->ix->device));
     hipEvent_t copied[2] = {nullptr, nullptr};
-    auto undo = on_exit([&]() { for (auto &e : copied) pool_event_release(e, false); });
-    for (auto &e : copied) HIP_TRY(pool_event_acquire(&e, false));
     skm_mapper::Piece waiting;
     bool have_waiting = false;
+    auto undo = on_exit([&]() {
+        // (an early return with a copy still queued: its block goes back to the pool with `waiting`)
+        if (have_waiting) (void)hipStreamSynchronize(m->packed_stream);
+        for (auto &e : copied) pool_event_release(e, false);
+    });
+    for (auto &e : copied) HIP_TRY(pool_event_acquire(&e, false));
     int waiting_stream = 0, turn = 0;
     auto land = [&]() -> int {                   // the piece whose copy was queued a call ago joins its stream
         if (!have_waiting) return SKM_OK;
