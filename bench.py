@@ -665,67 +665,6 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
     return line
 
 
-def samples_in_flight(args, ctx, n_samples=2, steps_each=3):
-    """Not `value`: the configs[1] step with `n_samples` samples in flight on the one GPU, each a thread with a
-    mapper of its own over the same resident reads and index -- the sample-level parallelism the reference has in
-    map_multiple_samples (seekmer/mapper.py:196-229, a ThreadPool over samples).  A single sample's EM is 121
-    dependent steps of small kernels during which most of the GPU idles; another sample's mapping fits there.
-    Every TPM must be the single-sample TPM bit for bit."""
-    import threading
-    from seekmer_amd import infer, mapper, synth
-    hip, _native, index, device = ctx['hip'], ctx['native'], ctx['index'], ctx['device']
-    n_units, read_len = SHAPES[1][0], SHAPES[1][1]
-    bases, offsets = synth.reads(args.seed, ctx['pool'], ctx['tx_offsets'], 0, n_units, read_len, True)
-    d_bases, d_offsets = ctypes.c_void_p(), ctypes.c_void_p()
-    _native.check(hip.skm_device_malloc(device, bases.size, ctypes.byref(d_bases)))
-    _native.check(hip.skm_device_malloc(device, offsets.size * 8, ctypes.byref(d_offsets)))
-    _native.check(hip.skm_device_upload(device, d_bases, bases.ctypes.data, bases.size))
-    _native.check(hip.skm_device_upload(device, d_offsets, offsets.ctypes.data, offsets.size * 8))
-    results = [mapper.MapResult(index, device=device) for _ in range(n_samples)]
-    tpms, failures = [None] * n_samples, []
-    start = threading.Barrier(n_samples + 1)
-
-    def sample(k):
-        try:
-            def step():
-                results[k].reset()
-                results[k].map_resident(d_bases, d_offsets, n_units, True, read_len)
-                tpms[k] = infer.quantify_resident(results[k])
-            step()                                  # warm-up
-            results[k].sync()
-            start.wait()
-            for _ in range(steps_each):
-                step()
-        except Exception as e:                      # noqa: BLE001  (reported below)
-            failures.append(repr(e))
-            start.abort()
-
-    threads = [threading.Thread(target=sample, args=(k,)) for k in range(n_samples)]
-    for t in threads:
-        t.start()
-    try:
-        start.wait()                                # (every thread has finished its warm-up step and waits here too)
-    except threading.BrokenBarrierError:
-        pass
-    t0 = time.perf_counter()
-    for t in threads:
-        t.join()
-    _native.check(hip.skm_device_synchronize(device))
-    elapsed = time.perf_counter() - t0
-    _native.check(hip.skm_device_free(device, d_bases))
-    _native.check(hip.skm_device_free(device, d_offsets))
-    if failures:
-        return {'error': failures[0]}
-    same = all(np.array_equal(t, tpms[0]) for t in tpms)
-    if not same:
-        raise SystemExit('parity check failed: samples mapped side by side give different TPM vectors')
-    return {'samples_in_flight': n_samples, 'steps_each': steps_each, 'value': n_samples * steps_each * n_units / elapsed,
-            'unit': 'pairs/s', 'ms_per_sample': 1e3 * elapsed / (n_samples * steps_each), 'tpm_identical': True,
-            'how': '%d threads, each a MapResult of its own over the same resident 10 M-pair batch and index, %d timed steps '
-                   '(reset -> pack -> map -> classes -> EM -> TPM) each after one warm-up; the reference\'s map_multiple_samples '
-                   'runs samples side by side in a ThreadPool' % (n_samples, steps_each)}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -833,9 +772,6 @@ def main():
             keep['parity_checked'] = sub['parity_checked']
             line['other_configs']['configs[%d]' % other if isinstance(other, int)
                                   else 'north_star: 50 M 2x100 pairs'] = keep
-        t0 = time.perf_counter()
-        line['two_samples_in_flight'] = samples_in_flight(args, ctx)
-        log('two samples in flight: %s (%.0fs with set-up)' % (line['two_samples_in_flight'].get('value'), time.perf_counter() - t0))
     if rank == 0:
         print(json.dumps(line), flush=True)
     if comm:
