@@ -120,6 +120,7 @@ struct skm_index {
     int device = 0;
     DevIndex d{};
     void *kmers = nullptr, *contigs = nullptr, *seq2 = nullptr, *targets = nullptr, *buckets = nullptr;
+    void *edge_kmers = nullptr;
     int64_t n_slots = 0, bytes = 0;
     int64_t layout[8] = {0};          // skm_index_layout
     int cu_count = 256;
@@ -547,7 +548,6 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     const int n_workers = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(
                               std::max(1u, std::thread::hardware_concurrency()), 16u), n_slots >> 20));
     std::vector<int64_t> empty_part((size_t)n_workers, 0), bad_part((size_t)n_workers, -1);
-    std::vector<int> absent_part((size_t)n_workers, 0);      // a slot holds the offset DevContig::succ reserves
     {
         std::vector<std::thread> workers;
         for (int w = 0; w < n_workers; ++w)
@@ -556,7 +556,6 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                 int64_t empty = 0;
                 for (int64_t i = first; i < last; ++i) {
                     if (hk[i].kmer == KMER_INVALID) { ++empty; continue; }
-                    if (hk[i].pos.offset == SUCC_ABSENT) absent_part[(size_t)w] = 1;
                     const int32_t e = hk[i].pos.entry < 0 ? ~hk[i].pos.entry : hk[i].pos.entry;
                     if (hk[i].pos.offset >= 0
                             && (e < 0 || e >= n_contigs || hk[i].pos.offset + K > hc[e].length)) {
@@ -569,12 +568,10 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
         for (auto &t : workers) t.join();
     }
     int64_t empty = 0;
-    bool successors_ok = true;
     for (int w = 0; w < n_workers; ++w) {
         if (bad_part[(size_t)w] >= 0)
             return fail(SKM_ERR_ARG, "k-mer slot %lld points outside its contig", (long long)bad_part[(size_t)w]);
         empty += empty_part[(size_t)w];
-        successors_ok = successors_ok && !absent_part[(size_t)w];
     }
     if (empty == 0) return fail(SKM_ERR_ARG, "k-mer table has no empty slot");
 
@@ -594,29 +591,37 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     HIP_TRY(hipMalloc((void **)&d_ascii, (size_t)n_bases));
     HIP_TRY(hipMemcpy(ix->kmers, kmers, (size_t)n_slots * sizeof(IndexEntry), hipMemcpyHostToDevice));
     int64_t n_overflow = 0;
-    {   // contig rows (skm_device.h: DevContig) and, behind them in the same allocation, the target
-        // slices that do not fit their row; of every target only the signed entry is kept
+    {   // contig records (skm_device.h: DevContig) and, behind them in the same allocation, the target
+        // slices that do not fit a side; of every target only the signed entry is kept
         std::vector<DevContig> rows((size_t)n_contigs);
+        std::vector<uint64_t> edges((size_t)n_contigs * 2);
         std::vector<int32_t> overflow;
         const Coord *ht = (const Coord *)targets;
         const int64_t row_words = (int64_t)sizeof(DevContig) / 4;      // (int32 words per record)
         for (int64_t c = 0; c < n_contigs; ++c) {
             DevContig &d = rows[(size_t)c];
             memset(&d, 0, sizeof(d));
-            d.offset = (int32_t)hc[c].offset;
-            d.length = (int32_t)hc[c].length;
-            d.target_length = (int32_t)hc[c].target_length;
-            d.first_kmer = hc[c].first_kmer;
-            d.last_kmer = hc[c].last_kmer;
+            edges[(size_t)(2 * c)] = hc[c].first_kmer;
+            edges[(size_t)(2 * c + 1)] = hc[c].last_kmer;
             const int64_t first = hc[c].target_offset, count = hc[c].target_length;
-            for (int j = 0; j < 8; ++j) d.succ[j] = Coord{0, SUCC_ABSENT};
-            if (count <= CONTIG_INLINE_TARGETS) {
-                d.target_offset = (int32_t)(c * row_words + CONTIG_TARGETS_WORD);
-                for (int64_t i = 0; i < count; ++i) d.targets[i] = ht[first + i].entry;
-                continue;
+            const int64_t place = n_contigs * row_words + (int64_t)overflow.size();
+            for (int s = 0; s < 2; ++s) {
+                DevSide &side = d.side[s];
+                side.offset = (int32_t)hc[c].offset;
+                side.length = (int32_t)hc[c].length;
+                // [0] the contig's last 8 bases (low bits of last_kmer), [1] its first 8 (top of first_kmer)
+                const uint32_t edge8 = s == 0 ? (uint32_t)(hc[c].last_kmer & 0xffffu)
+                                              : (uint32_t)(hc[c].first_kmer >> (2 * K - 16)) & 0xffffu;
+                side.count_edge = ((uint32_t)std::min<int64_t>(count, 0xffff) << 16) | edge8;
+                if (count <= CONTIG_INLINE_TARGETS) {
+                    for (int64_t i = 0; i < count; ++i) side.targets[i] = ht[first + i].entry;
+                } else {
+                    side.targets[0] = (int32_t)place;
+                    side.targets[1] = (int32_t)count;
+                }
             }
-            d.target_offset = (int32_t)(n_contigs * row_words + (int64_t)overflow.size());
-            for (int64_t i = 0; i < count; ++i) overflow.push_back(ht[first + i].entry);
+            if (count > CONTIG_INLINE_TARGETS)
+                for (int64_t i = 0; i < count; ++i) overflow.push_back(ht[first + i].entry);
         }
         n_overflow = (int64_t)overflow.size();
         const size_t row_bytes = (size_t)n_contigs * sizeof(DevContig);
@@ -625,6 +630,8 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
         if (n_overflow)
             HIP_TRY(hipMemcpy((char *)ix->contigs + row_bytes, overflow.data(), (size_t)n_overflow * sizeof(int32_t),
                               hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&ix->edge_kmers, (edges.size() + 2) * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(ix->edge_kmers, edges.data(), edges.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpy(d_ascii, sequences, (size_t)n_bases, hipMemcpyHostToDevice));
     launch_pack_sequences(d_ascii, n_bases, (uint64_t *)ix->seq2, n_words, nullptr);
@@ -640,12 +647,13 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
     ix->d.seq2 = (const uint64_t *)ix->seq2;
     ix->d.n_bases = n_bases;
     ix->d.targets = (const int32_t *)ix->contigs;       // (rows and overflow slices as one int32 array)
+    ix->d.edge_kmers = (const uint64_t *)ix->edge_kmers;
     ix->d.n_targets = n_targets;
     ix->d.max_target_count = (int32_t)std::max<int64_t>(max_tc, 1);
     ix->d.edge_windows = edge_windows ? 1 : 0;
     ix->d.sorted_targets = sorted_targets ? 1 : 0;
     ix->bytes = n_slots * (int64_t)sizeof(IndexEntry) + n_contigs * (int64_t)sizeof(DevContig)
-                + n_overflow * (int64_t)sizeof(int32_t) + n_words * 8;
+                + n_overflow * (int64_t)sizeof(int32_t) + n_words * 8 + n_contigs * 16;
     {   // the same set of k-mers by bucket (skm_device.h: DevBucket): about one k-mer per bucket
         const int64_t occupied = n_slots - empty;
         uint64_t n_buckets = 16;
@@ -676,10 +684,13 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                 ix->bytes += (int64_t)n_buckets * (int64_t)sizeof(DevBucket);
                 ix->layout[0] = 1;
                 const char *no_succ = getenv("SKM_NO_SUCCESSORS");     // tuning aid: every junction k-mer looked up
-                if (successors_ok && !(no_succ && no_succ[0] == '1')) {
+                if (!(no_succ && no_succ[0] == '1')) {
                     // junction successors of every contig record (skm_device.h: DevContig), by the
-                    // lookup the kernels would do
-                    launch_successor_build(ix->d, (DevContig *)ix->contigs, n_contigs, nullptr);
+                    // lookup the kernels would do.  SKM_TEST_SUCC_LOOKUP=1 (test hook) marks them all
+                    // "look it up", so that every hop takes the fall-back a real index hardly ever needs.
+                    const char *force = getenv("SKM_TEST_SUCC_LOOKUP");
+                    launch_successor_build(ix->d, (DevContig *)ix->contigs, n_contigs, force && force[0] == '1',
+                                           nullptr);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipDeviceSynchronize());
                     ix->d.successors = 1;
@@ -702,7 +713,7 @@ extern "C" int skm_index_destroy(skm_index *ix)
     if (ix->holders.fetch_sub(1) > 1) return SKM_OK;      // a mapper still maps against it
     (void)hipSetDevice(ix->device);
     (void)hipFree(ix->kmers); (void)hipFree(ix->contigs); (void)hipFree(ix->targets); (void)hipFree(ix->seq2);
-    (void)hipFree(ix->buckets);
+    (void)hipFree(ix->buckets); (void)hipFree(ix->edge_kmers);
     delete ix;
     return SKM_OK;
 }

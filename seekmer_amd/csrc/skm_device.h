@@ -30,41 +30,52 @@ struct ContigEntry {                                             // _common.pxd:
 // Contig record as the kernels read it.  The mapper runs at the chip's random sector-request
 // ceiling, so what counts is how many 64-byte sectors a contig visit touches and how many
 // DEPENDENT round trips a read needs.  The 48-byte reference row is therefore re-packed at upload
-// to a 128-byte record of two sectors:
-//   * sector 0, the row: the reference's fields and the contig's first CONTIG_INLINE_TARGETS
-//     signed target entries behind them (nine slices in ten have no more than eight): the row's
-//     target_offset points into its own sector, the list arrives with the row, and a merge
-//     (KMerIndex.map_contig / _filter_on_contig, _common.pyx:143-235) is one round trip instead
-//     of two.  Longer slices live behind the records in the same allocation; `DevIndex::targets`
-//     addresses records and overflow alike as one int32 array (row c's inline entries are
-//     elements 32 c + 8 .. 32 c + 15).
-//   * sector 1, the junction successors.  Every hop of _filter_targets_to_left/right
-//     (_mapper.pyx:246-248, :308-310) looks up ONE k-mer that is a pure function of (contig,
-//     end, orientation, read base): prepend / append of the anchor contig's edge k-mer
-//     (get_tail_kmer, _common.pyx:241-266) with the next base of the read.  There are eight such
-//     k-mers per contig -- `succ[b]` = map_kmer(append(tail k-mer at the contig's end, b)),
-//     `succ[4 + b]` = map_kmer(prepend(first_kmer, b)); an anchor on the reverse strand asks for
-//     the reverse complement of one of the same eight, whose answer is the stored one with the
-//     entry complemented (map_kmer, _common.pyx:84-87) -- so their map_kmer results are computed
-//     once at upload, with the device's own lookup, and a hop reads its answer from the record
-//     of the contig it is leaving: no visit to the k-mer table, one dependent round trip less
-//     per hop.  Stored exactly as map_kmer returns them (entries that hold a position with
-//     offset < 0 included: a stale anchor is part of the result); "not in the
-//     table" is SUCC_ABSENT, which no position of a validated index can be.
-constexpr int CONTIG_INLINE_TARGETS = 8;
+// to a 128-byte record of two sectors, ONE PER END OF THE CONTIG, each holding everything a visit
+// that works at that end needs:
+//   * the contig's place in the pooled bases and its length (both sides carry them);
+//   * the 8 bases at this end (the window the alignment step of a hop compares,
+//     get_contig_sequence of an edge k-mer, _common.pyx:103-137);
+//   * the junction successors of this end.  Every hop of _filter_targets_to_left/right
+//     (_mapper.pyx:246-248, :308-310) looks up ONE k-mer that is a pure function of (contig, end,
+//     orientation, read base): prepend / append of the anchor contig's edge k-mer (get_tail_kmer,
+//     _common.pyx:241-266) with the next base of the read.  There are four such k-mers per end --
+//     END side: append(tail k-mer at the contig's end, b); START side: prepend(first_kmer, b) -- and
+//     an anchor on the reverse strand asks for the reverse complement of one of the same, whose
+//     answer is the stored one with the entry complemented (map_kmer, _common.pyx:84-87).  Their
+//     map_kmer results are computed once at upload, with the device's own lookup, and a hop reads
+//     its answer from the record of the contig it is leaving: no visit to the k-mer table.  In a
+//     built index such a k-mer is the first k-mer of the contig it belongs to or the last one (that
+//     is what makes it a junction), so a successor is one word: the signed contig entry and, in the
+//     two low bits, SUCC_ABSENT (not in the table: a miss, _mapper.pyx:250, :312), SUCC_AT_START
+//     (offset 0), SUCC_AT_END (offset = that contig's length - k, filled in when the hop lands
+//     there and its record has arrived) or SUCC_LOOKUP (any other offset, or a k-mer stored without
+//     a position: the hop does the table lookup itself, as every hop did before);
+//   * the contig's first CONTIG_INLINE_TARGETS signed target entries (nine slices in ten have no
+//     more): the list arrives with the sector, and a merge (KMerIndex.map_contig /
+//     _filter_on_contig, _common.pyx:143-235) is one round trip.  Longer slices live behind the
+//     records in the same allocation and the sector holds their place and length instead;
+//     `DevIndex::targets` addresses records and overflow alike as one int32 array.
+// Which side a visit reads follows from its direction and the anchor's orientation: moving right on
+// a forward anchor, or left on a reverse one, works at the contig's END (side 0), the other two at its
+// START (side 1) -- and the merge that lands a hop on a contig is followed by the alignment step at
+// the same end, so a contig a read hops through costs ONE sector where a record of a row sector + a
+// successor sector (the first layout of round 4) cost two.  What only the fall-back paths need -- the
+// two edge k-mers themselves, for a hop that must look its junction k-mer up -- lives in an array of
+// its own (DevIndex::edge_kmers).
+constexpr int CONTIG_INLINE_TARGETS = 9;
 constexpr int CONTIG_SHIFT = 7;
-constexpr int32_t SUCC_ABSENT = INT32_MIN;
-struct alignas(128) DevContig {
-    int32_t offset, length;            // into the pooled bases
-    int32_t target_offset, target_length;
-    uint64_t first_kmer, last_kmer;
-    int32_t targets[CONTIG_INLINE_TARGETS];
-    Coord succ[8];                     // [0..3] right of the contig's end, [4..7] left of its start
+constexpr uint32_t SUCC_ABSENT = 0, SUCC_AT_START = 1, SUCC_AT_END = 2, SUCC_LOOKUP = 3;
+constexpr int32_t OFFSET_AT_END = INT32_MAX;   // Coord.offset of a successor until its contig's length is known
+struct alignas(64) DevSide {
+    int32_t offset, length;            // the contig in the pooled bases
+    uint32_t count_edge;               // min(target_length, 0xffff) << 16 | the 8 bases at this end (first on top)
+    int32_t succ[4];                   // entry << 2 | SUCC_* of the four junction k-mers of this end
+    int32_t targets[CONTIG_INLINE_TARGETS];   // the slice; or [0] = its place in DevIndex::targets, [1] = its length
 };
-constexpr int CONTIG_TARGETS_WORD = 8;      // offsetof(DevContig, targets) / 4
-static_assert(sizeof(DevContig) == (1u << CONTIG_SHIFT), "contig_at shifts by CONTIG_SHIFT");
-static_assert(offsetof(DevContig, targets) == 4 * CONTIG_TARGETS_WORD && offsetof(DevContig, succ) == 64,
-              "the row is sector 0, the successors sector 1");
+struct alignas(128) DevContig { DevSide side[2]; };      // [0] the contig's end, [1] its start
+constexpr int SIDE_WORDS = 16, SIDE_TARGETS_WORD = 7;    // int32 words per side / offsetof(DevSide, targets) / 4
+static_assert(sizeof(DevSide) == 64 && sizeof(DevContig) == (1u << CONTIG_SHIFT), "a side is one sector");
+static_assert(offsetof(DevSide, targets) == 4 * SIDE_TARGETS_WORD, "the inline targets close the sector");
 
 // The k-mer table as the mapper probes it.  The reference's table (linear
 // probing from a SipHash home slot, _common.pyx:54-97) is a set: a built index
@@ -107,6 +118,7 @@ struct DevIndex {
     int32_t edge_windows;      // first_kmer/last_kmer agree with the pooled bases on every contig
     int32_t sorted_targets;    // every contig's target slice ascends by signed entry (built indices do)
     int32_t successors;        // every record carries its junction successors (see DevContig)
+    const uint64_t *edge_kmers; // [2 * n_contigs]: first_kmer, last_kmer of every contig (fall-back paths)
     const DevBucket *buckets;  // the same set of k-mers by bucket, or nullptr (see DevBucket)
     uint32_t bucket_mask;      // number of buckets - 1 (a power of two)
     uint32_t bucket_shift;     // bucket = bucket_hash(canonical k-mer) >> bucket_shift
@@ -118,10 +130,21 @@ __device__ __forceinline__ Coord invalid_coord() { return Coord{0, -1}; }  // _c
 // (wave-uniform) base pointer: scalar base + vector offset addressing instead
 // of a 64-bit address computation per access (skm_index_create bounds
 // n_contigs by 2^26).
-__device__ __forceinline__ const DevContig &contig_at(const DevIndex &ix, int32_t index)
+__device__ __forceinline__ const DevSide &side_at(const DevIndex &ix, int32_t index, int side)
 {
-    return *reinterpret_cast<const DevContig *>(reinterpret_cast<const char *>(ix.contigs)
-                                                + ((uint32_t)index << CONTIG_SHIFT));
+    return *reinterpret_cast<const DevSide *>(reinterpret_cast<const char *>(ix.contigs)
+                                              + (((uint32_t)index << CONTIG_SHIFT) + ((uint32_t)side << 6)));
+}
+// the end of its contig a visit works at: moving right on a forward anchor or left on a reverse one -> 0 (END)
+__device__ __forceinline__ int visit_side(bool right, bool forward) { return right == forward ? 0 : 1; }
+// a contig's target slice as one of its sides gives it: first element in DevIndex::targets, length
+struct Slice { int32_t start, length; };
+__device__ __forceinline__ Slice side_slice(const DevSide &s, int32_t index, int side)
+{
+    const int32_t count = (int32_t)(s.count_edge >> 16);
+    if (count <= CONTIG_INLINE_TARGETS)
+        return Slice{index * (2 * SIDE_WORDS) + side * SIDE_WORDS + SIDE_TARGETS_WORD, count};
+    return Slice{s.targets[0], s.targets[1]};
 }
 
 // _kmer.pxd:146-171: reverse the 2-bit groups of the 64-bit word, shift the
@@ -288,48 +311,67 @@ __device__ __forceinline__ Coord map_kmer_buckets(const DevIndex &ix, uint64_t k
     return map_kmer_buckets(ix, kmer, found);
 }
 
-// The k-mer whose map_kmer result DevContig::succ[j] holds (see DevContig): the junction k-mers of
-// _filter_targets_to_right (j < 4: _kmer.append of the tail k-mer at the contig's end with base j,
-// _mapper.pyx:308-310) and of _filter_targets_to_left (j >= 4: _kmer.prepend of first_kmer with base
-// j - 4, :246-248) for an anchor on the forward strand.  get_tail_kmer (_common.pyx:241-266) tells
-// the two edge k-mers apart by `offset == 0`, so a contig of exactly k bases has first_kmer at its end too.
-__device__ __forceinline__ uint64_t successor_query(const DevContig &row, int j)
+// The k-mer whose map_kmer result side `side`, successor `b` of a record holds (see DevContig): the
+// junction k-mers of _filter_targets_to_right (END side: _kmer.append of the tail k-mer at the
+// contig's end with base b, _mapper.pyx:308-310) and of _filter_targets_to_left (START side:
+// _kmer.prepend of first_kmer with base b, :246-248) for an anchor on the forward strand.
+// get_tail_kmer (_common.pyx:241-266) tells the two edge k-mers apart by `offset == 0`, so a contig
+// of exactly k bases has first_kmer at its end too.
+__device__ __forceinline__ uint64_t successor_query(uint64_t first_kmer, uint64_t last_kmer, int32_t length,
+                                                    int side, int b)
 {
-    const uint64_t tail_end = row.length == K ? row.first_kmer : row.last_kmer;
-    if (j < 4) return ((tail_end << 2) | (uint64_t)j) & KMER_MASK;
-    return (row.first_kmer >> 2) | ((uint64_t)(j - 4) << (2 * K - 2));
+    const uint64_t tail_end = length == K ? first_kmer : last_kmer;
+    if (side == 0) return ((tail_end << 2) | (uint64_t)b) & KMER_MASK;
+    return (first_kmer >> 2) | ((uint64_t)b << (2 * K - 2));
 }
 
-// map_kmer of the junction k-mer of a hop that leaves the anchor's contig: to the RIGHT
+// map_kmer of the junction k-mer of a hop that leaves the anchor's contig: to the right
 // (append(get_tail_kmer(anchor), base), anchor on the contig's last k-mer in read direction) or to the
-// left (prepend(get_tail_kmer(anchor), base), anchor on its first).  A reverse anchor's k-mer is
-// the reverse complement of a forward one with the complementary base, and map_kmer of a reverse
-// complement is the same slot's position with the entry complemented.
-// The four candidates of a hop (32 bytes, half of the record's second sector) are requested when the
-// action starts, together with the row: which of them the hop takes is known only after the 8-base
-// alignment step, and a load issued then would be one more dependent round trip.
-struct SuccessorQuad { u32x4 lo, hi; };      // Coord 0 = lo.xy, 1 = lo.zw, 2 = hi.xy, 3 = hi.zw
+// left (prepend(get_tail_kmer(anchor), base), anchor on its first), from the four successors of the
+// side the step works at.  A reverse anchor's k-mer is the reverse complement of a forward one with
+// the complementary base, and map_kmer of a reverse complement is the same position with the entry
+// complemented.  `kind` tells what the offset is (SUCC_*); the Coord's offset is 0 or OFFSET_AT_END.
+// What a step of a filter (or the first hit's list) reads of the anchor's contig: one sector, every
+// field asked for before the first of them is used.
+struct SideVisit {
+    int32_t offset, length;
+    uint32_t edge8;
+    int32_t succ[4];
+    Slice slice;
+};
 template <bool RIGHT>
-__device__ __forceinline__ SuccessorQuad load_successors(const DevIndex &ix, Coord anchor, bool wanted)
-{
-    SuccessorQuad q{{0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (wanted) {
-        const bool forward = anchor.entry >= 0;
-        const int32_t index = forward ? anchor.entry : ~anchor.entry;
-        const u32x4 *p = reinterpret_cast<const u32x4 *>(&contig_at(ix, index).succ[RIGHT == forward ? 0 : 4]);
-        q.lo = p[0];
-        q.hi = p[1];
-    }
-    return q;
-}
-__device__ __forceinline__ Coord junction_successor(const SuccessorQuad &q, Coord anchor, uint32_t base)
+__device__ __forceinline__ SideVisit visit(const DevIndex &ix, Coord anchor, bool successors, bool list)
 {
     const bool forward = anchor.entry >= 0;
+    const int32_t index = forward ? anchor.entry : ~anchor.entry;
+    const int side = visit_side(RIGHT, forward);
+    const DevSide &record = side_at(ix, index, side);
+    SideVisit v;
+    v.offset = record.offset;
+    v.length = record.length;
+    const uint32_t count_edge = record.count_edge;
+    v.succ[0] = v.succ[1] = v.succ[2] = v.succ[3] = 0;
+    if (successors) {
+        v.succ[0] = record.succ[0]; v.succ[1] = record.succ[1]; v.succ[2] = record.succ[2]; v.succ[3] = record.succ[3];
+    }
+    v.slice = Slice{0, 0};
+    if (list) {
+        const int32_t place = record.targets[0], longer = record.targets[1];
+        const int32_t count = (int32_t)(count_edge >> 16);
+        v.slice = count <= CONTIG_INLINE_TARGETS
+                      ? Slice{index * (2 * SIDE_WORDS) + side * SIDE_WORDS + SIDE_TARGETS_WORD, count}
+                      : Slice{place, longer};
+    }
+    v.edge8 = count_edge & 0xffffu;
+    return v;
+}
+__device__ __forceinline__ Coord junction_successor(const int32_t (&succ)[4], bool forward, uint32_t base, uint32_t &kind)
+{
     const uint32_t b = forward ? base : 3u - base;
-    const uint32_t entry = b == 0 ? q.lo.x : b == 1 ? q.lo.z : b == 2 ? q.hi.x : q.hi.z;
-    const uint32_t offset = b == 0 ? q.lo.y : b == 1 ? q.lo.w : b == 2 ? q.hi.y : q.hi.w;
-    if ((int32_t)offset == SUCC_ABSENT) return invalid_coord();
-    return Coord{(int32_t)(forward ? entry : ~entry), (int32_t)offset};
+    const int32_t word = b == 0 ? succ[0] : b == 1 ? succ[1] : b == 2 ? succ[2] : succ[3];
+    kind = (uint32_t)word & 3u;
+    const int32_t entry = word >> 2;
+    return Coord{forward ? entry : ~entry, kind == SUCC_AT_START ? 0 : OFFSET_AT_END};
 }
 
 // 32 consecutive 2-bit codes starting at base `p` of a packed array (first
@@ -357,10 +399,9 @@ __device__ __forceinline__ uint32_t revcomp8(uint32_t v)
 // read orientation, as 16 bits (first base on top).  The pool index is
 // clamped so that an inconsistent index can never fault the GPU.
 template <bool STATS>
-__device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, bool leading, LaneStats *st)
+__device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, int32_t contig_offset, bool leading, LaneStats *st)
 {
-    int32_t index = c.entry < 0 ? ~c.entry : c.entry;
-    int64_t offset = (int64_t)contig_at(ix, index).offset + c.offset;
+    int64_t offset = (int64_t)contig_offset + c.offset;
     if (STATS) { st->contig_reads++; st->seq_fetches++; }
     if (c.entry >= 0) offset += leading ? ALIGN_LENGTH : K;
     else offset += leading ? K : ALIGN_LENGTH;
@@ -375,22 +416,19 @@ __device__ __forceinline__ uint32_t contig8(const DevIndex &ix, Coord c, bool le
 // The same window when the anchor sits on the first or last k-mer of its contig
 // (every in-loop step of _filter_targets_to_left/right, _mapper.pyx:229-246 and
 // :285-308, moves it there): the contig's first 8 bases are the top 16 bits of
-// first_kmer and its last 8 the low 16 bits of last_kmer, so the record that
-// was fetched for the move already holds the window and the pool is not
+// first_kmer and its last 8 the low 16 bits of last_kmer, copied at upload into
+// the side the step reads anyway (DevSide::count_edge), so the pool is not
 // touched.  skm_index_create checks first_kmer/last_kmer against the pooled
 // bases; an index where they disagree takes the pool path (edge_windows = 0).
+// The side is the one of the step's direction (SideVisit): leading windows belong
+// to left steps, trailing ones to right steps.
 template <bool STATS>
-__device__ __forceinline__ uint32_t contig8_edge(const DevIndex &ix, Coord c, bool leading, LaneStats *st)
+__device__ __forceinline__ uint32_t contig8_edge(const DevIndex &ix, Coord c, const SideVisit &at_side, bool leading,
+                                                 LaneStats *st)
 {
-    if (!ix.edge_windows) return contig8<STATS>(ix, c, leading, st);
-    const int32_t index = c.entry < 0 ? ~c.entry : c.entry;
+    if (!ix.edge_windows) return contig8<STATS>(ix, c, at_side.offset, leading, st);
     if (STATS) { st->contig_reads++; st->seq_fetches++; }
-    const bool forward = c.entry >= 0;
-    uint32_t v;
-    if (forward == leading) v = (uint32_t)(contig_at(ix, index).first_kmer >> (2 * K - 16)) & 0xffffu;
-    else v = (uint32_t)contig_at(ix, index).last_kmer & 0xffffu;
-    if (!forward) v = revcomp8(v);
-    return v;
+    return c.entry < 0 ? revcomp8(at_side.edge8) : at_side.edge8;
 }
 
 // KMerIndex.get_tail_kmer, _common.pyx:241-266
@@ -399,7 +437,7 @@ __device__ __forceinline__ uint64_t tail_kmer(const DevIndex &ix, Coord c, LaneS
 {
     int32_t index = c.entry < 0 ? ~c.entry : c.entry;
     if (STATS) st->contig_reads++;
-    uint64_t k = c.offset == 0 ? contig_at(ix, index).first_kmer : contig_at(ix, index).last_kmer;
+    uint64_t k = ix.edge_kmers[2 * (int64_t)index + (c.offset == 0 ? 0 : 1)];
     if (c.entry < 0) k = kmer_revcomp(k);
     return k;
 }

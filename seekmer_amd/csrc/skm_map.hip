@@ -279,18 +279,31 @@ probe_check_kernel(DevIndex ix, uint64_t n_slots, unsigned long long *report)
     if (bad) atomicAdd(&report[3], bad);
 }
 
-// The junction successors of every contig record (DevContig::succ), by the device's own lookup over
-// the bucket table that has just passed its check: eight lanes per contig.
+// The junction successors of every contig record (DevSide::succ), by the device's own lookup over
+// the bucket table that has just passed its check: eight lanes per contig.  `force_lookup` (a test
+// hook) marks every successor that exists SUCC_LOOKUP, so that the hops take the fall-back path.
 __global__ void __launch_bounds__(256)
-successor_build_kernel(DevIndex ix, DevContig *records, int64_t n_contigs)
+successor_build_kernel(DevIndex ix, DevContig *records, int64_t n_contigs, int force_lookup)
 {
     for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n_contigs * 8;
          g += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = g >> 3;
-        const int j = (int)(g & 7);
+        const int side = (int)(g & 7) >> 2, b = (int)(g & 3);
         bool found;
-        const Coord pos = map_kmer_buckets(ix, successor_query(records[c], j), found);
-        records[c].succ[j] = found ? pos : Coord{0, SUCC_ABSENT};
+        const Coord pos = map_kmer_buckets(ix, successor_query(ix.edge_kmers[2 * c], ix.edge_kmers[2 * c + 1],
+                                                               records[c].side[0].length, side, b), found);
+        // (a k-mer stored without a position, offset < 0, is a miss that leaves its own trace in the
+        // unit's anchor: SURVEY A6 -- left to the lookup)
+        uint32_t kind = found ? SUCC_LOOKUP : SUCC_ABSENT;
+        if (found && pos.offset >= 0 && !force_lookup) {
+            const int64_t landing = pos.entry < 0 ? ~pos.entry : pos.entry;
+            if (landing < n_contigs) {
+                if (pos.offset == 0) kind = SUCC_AT_START;
+                else if (pos.offset == records[landing].side[0].length - K) kind = SUCC_AT_END;
+            }
+        }
+        const bool placed = kind == SUCC_AT_START || kind == SUCC_AT_END;
+        records[c].side[side].succ[b] = (int32_t)((placed ? (uint32_t)pos.entry << 2 : 0u) | kind);
     }
 }
 
@@ -339,13 +352,14 @@ struct Span {               // MappedSpan, _common.pxd:31-35 (targets = TSet, n 
 };
 
 // KMerIndex.map_contig, _common.pyx:143-179: the list is the whole slice
+// (from the side of the record that the step after the first hit reads: SideVisit)
 template <bool STATS>
-__device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, TSet &set, Span &span, LaneStats *st)
+__device__ __forceinline__ void map_contig(const DevIndex &ix, Coord c, const SideVisit &at_side, TSet &set, Span &span,
+                                           LaneStats *st)
 {
     const bool forward = c.entry >= 0;
-    const int32_t index = forward ? c.entry : ~c.entry;
-    set.start = (int32_t)contig_at(ix, index).target_offset;
-    int32_t length = (int32_t)contig_at(ix, index).target_length;
+    set.start = at_side.slice.start;
+    int32_t length = at_side.slice.length;
     if (length > ix.max_target_count) length = ix.max_target_count;
     set.length = length;
     set.forward = forward;
@@ -451,15 +465,22 @@ __device__ __forceinline__ uint32_t keep_common(const int32_t (&a)[N], const int
 // KMerIndex._filter_on_contig, _common.pyx:185-235: two-pointer merge of the
 // list (ascending signed entries) with the anchor contig's slice; an empty
 // intersection leaves the list as it was and returns false.
+// `right`: the merge belongs to a hop to the right; the step that follows reads the same side of the
+// record.  A successor that landed on its contig's last k-mer gets its offset here (OFFSET_AT_END).
 template <bool STATS>
-__device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, TSet &set, Span &span, LaneStats *st)
+__device__ __forceinline__ bool filter_on_contig(const DevIndex &ix, bool right, TSet &set, Span &span, LaneStats *st)
 {
     if (STATS) st->merges++;
-    if (span.n == 0) return true;
     const bool forward = span.anchor.entry >= 0;
     const int32_t contig = forward ? span.anchor.entry : ~span.anchor.entry;
-    const int32_t start = (int32_t)contig_at(ix, contig).target_offset;
-    const int32_t length = (int32_t)contig_at(ix, contig).target_length;
+    const int side = visit_side(right, forward);
+    const DevSide &record = side_at(ix, contig, side);
+    if (span.anchor.offset == OFFSET_AT_END) span.anchor.offset = record.length - K;
+    if (span.n == 0) return true;
+    const Slice slice = side_slice(record, contig, side);
+    const int32_t start = slice.start;
+    int32_t length = slice.length;
+    if (length > ix.max_target_count) length = ix.max_target_count;
     if (STATS) st->contig_reads++;
     if (LIST_FAST(STATS) && ix.sorted_targets && set.length <= LIST_REGS && length <= LIST_REGS) {
         if (length == 0) return false;
@@ -598,19 +619,6 @@ __device__ __forceinline__ int sift4_right(uint32_t ref8, const QWindow &q, int 
     return 0;
 }
 
-__device__ __forceinline__ int left_move(const DevIndex &ix, Coord a)
-{
-    const bool forward = a.entry >= 0;
-    const int32_t contig = forward ? a.entry : ~a.entry;
-    return forward ? a.offset : (int)contig_at(ix, contig).length - a.offset - K;
-}
-__device__ __forceinline__ int right_move(const DevIndex &ix, Coord a)
-{
-    const bool forward = a.entry >= 0;
-    const int32_t contig = forward ? a.entry : ~a.entry;
-    return forward ? (int)contig_at(ix, contig).length - a.offset - K : a.offset;
-}
-
 // _intersect, _mapper.pyx:350-397: mate 1 ascending against mate 2 walked from
 // its end with complemented entries; matches are consumed one to one.
 template <bool STATS>
@@ -708,7 +716,7 @@ __device__ __forceinline__ uint64_t tuple_key_step(uint64_t h, uint32_t id)
 // caused them.
 enum : int { ST_IDLE = 0, ST_NEW,
              Y_FIRST, Y_LJ, Y_LS, Y_RA, Y_RJ,          // want a lookup
-             M_LJ, M_LS, M_RJ,                         // want a list merge
+             M_LJ, M_LS, M_RJ, M_FIRST,                // want a list merge (M_FIRST: only the first hit's list)
              N_LEFT, N_RIGHT,                          // want an 8-base alignment step
              N_RIGHT_ENTER, N_AFTER, N_MATE_DONE,      // cheap transitions
              ST_UNIT_DONE,                             // want emission
@@ -728,7 +736,7 @@ __device__ __forceinline__ int action_of(int state)
     if (state >= Y_FIRST && state <= Y_RJ) return A_LOOKUP;
     if (state == Y_SCAN) return A_SCAN;
     if (state == ST_NEW) return A_START;
-    if (state >= M_LJ && state <= M_RJ) return A_MERGE;
+    if (state >= M_LJ && state <= M_FIRST) return A_MERGE;
     if (state == N_LEFT) return A_LEFT;
     if (state == N_RIGHT) return A_RIGHT;
     return A_EMIT;                                    // ST_UNIT_DONE
@@ -912,6 +920,28 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 tail_acgt = acgt >> 8;
             };
             bool anchored = false;      // span.anchor is map_kmer(k-mer at span.end) already
+            // _find_first_kmer has found its k-mer at read position scan_i - K (:203-206, :211-214).
+            // KMerIndex.map_contig's list is NOT fetched here: the record of the contig would be a
+            // second dependent access behind the bucket's, and the alignment step that follows reads
+            // the same sector anyway -- it takes the list along (set.length < 0 = "list to come"; the
+            // counting build fetches it here, as the reference does).
+            auto first_hit = [&](Coord pos) {
+                span.begin = scan_i - K;
+                span.end = span.begin;
+                if (COUNT) {
+                    map_contig<STATS>(ix, pos, span.begin > 0 ? visit<false>(ix, pos, false, true)
+                                                              : visit<true>(ix, pos, false, true), set, span, &ls);
+                } else {
+                    set.start = 0; set.length = -1; set.forward = pos.entry >= 0; set.word0 = 0;
+                    span.n = 1;
+                }
+                state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
+                anchored = true;
+                if (SUCCESSORS && state == N_LEFT) {
+                    kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
+                    first_hit_kept = 1;
+                }
+            };
 
             if (valid && action == A_START) {
                 rv = read_view(block_records, b.record_words, b.words_per_read, first_read + (uint32_t)mate);
@@ -936,15 +966,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 span.anchor = pos;
                 if (state == Y_FIRST) {                       // _find_first_kmer, :199-216
                     if (pos.offset >= 0) {
-                        span.begin = scan_i - K;
-                        span.end = span.begin;
-                        map_contig<STATS>(ix, pos, set, span, &ls);
-                        state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
-                        anchored = true;
-                        if (SUCCESSORS && state == N_LEFT) {
-                            kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
-                            first_hit_kept = 1;
-                        }
+                        first_hit(pos);
                     } else if (scan_i < rv.len) {
                         kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;   // _kmer.append
                         ++scan_i;
@@ -1012,15 +1034,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 scan_i += last;
                 span.anchor = pos;
                 if (pos.offset >= 0) {
-                    span.begin = scan_i - K;
-                    span.end = span.begin;
-                    map_contig<STATS>(ix, pos, set, span, &ls);
-                    state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
-                    anchored = true;
-                    if (SUCCESSORS && state == N_LEFT) {
-                        kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
-                        first_hit_kept = 1;
-                    }
+                    first_hit(pos);
                 } else if (scan_i < rv.len) {
                     if ((scan_i >> 4) != ((scan_i - last) >> 4)) look = read_half(rv, scan_i >> 4);
                     kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
@@ -1035,15 +1049,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     const Coord pos = lookup_kmer<STATS, BUCKETS>(ix, kmer, &ls);
                     span.anchor = pos;
                     if (pos.offset >= 0) {
-                        span.begin = scan_i - K;
-                        span.end = span.begin;
-                        map_contig<STATS>(ix, pos, set, span, &ls);
-                        state = span.n == 0 ? N_MATE_DONE : (span.begin > 0 ? N_LEFT : N_RIGHT_ENTER);
-                        anchored = true;
-                        if (SUCCESSORS && state == N_LEFT) {
-                            kmer = ((uint64_t)(uint32_t)pos.offset << 32) | (uint32_t)pos.entry;
-                            first_hit_kept = 1;
-                        }
+                        first_hit(pos);
                     } else if (scan_i < rv.len) {
                         kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
                         ++scan_i;
@@ -1054,105 +1060,146 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 }
             } else if (valid && action == A_MERGE) {
                 // ---------------------------------- the one _filter_on_contig site
-                const bool ok = filter_on_contig<COUNT>(ix, set, span, &ls);
-                if (state == M_LJ) {
-                    if (ok) state = N_LEFT;
-                    else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
-                    else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
-                } else if (state == M_LS) {
-                    if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
+                if (state == M_FIRST) {                       // a first hit that no step follows (see N_RIGHT_ENTER)
+                    map_contig<STATS>(ix, span.anchor, visit<true>(ix, span.anchor, false, true), set, span, &ls);
+                    state = span.n == 0 ? N_MATE_DONE : N_AFTER;
                 } else {
-                    if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
+                    const bool ok = filter_on_contig<COUNT>(ix, state == M_RJ, set, span, &ls);
+                    if (state == M_LJ) {
+                        if (ok) state = N_LEFT;
+                        else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }
+                        else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
+                    } else if (state == M_LS) {
+                        if (ok) state = N_LEFT; else { span.n = 0; state = N_AFTER; }
+                    } else {
+                        if (ok) state = N_RIGHT; else { span.n = 0; state = N_AFTER; }
+                    }
                 }
             } else if (valid && action == A_LEFT) {
                 // --------------- _filter_targets_to_left: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
-                // (a forward anchor's distance to the contig's left edge is its offset: whether this
-                // is a hop is then known before the row arrives, and a closing check asks for no successors)
-                const SuccessorQuad next = load_successors<false>(ix, span.anchor,
-                                                                  SUCCESSORS && (!forward || span.begin > span.anchor.offset));
-                const int move = left_move(ix, span.anchor);
-                if (STATS) ls.contig_reads++;
-                const bool in_loop = span.begin > move;
-                int at;
-                if (in_loop) {
-                    span.begin -= move;
-                    span.anchor.offset -= forward ? move : -move;
-                    at = span.begin;
-                } else {                                      // closing check, :270-275
-                    span.anchor.offset -= forward ? span.begin : -span.begin;
-                    at = 0;
-                }
-                // (the closing check compares read bases 0..7: kept with the context)
-                const QWindow q = in_loop ? left_window(rv, at) : edge_window(edge & 0xffffu, head_acgt, 0);
-                const int shift = sift4_left(in_loop ? contig8_edge<STATS>(ix, span.anchor, true, &ls)
-                                                     : contig8<STATS>(ix, span.anchor, true, &ls), q, at);
-                if (!in_loop) {
-                    if (shift == INVALID_SHIFT) span.n = 0;
-                    state = N_RIGHT_ENTER;
-                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
-                    span.n = 0;
-                    state = N_AFTER;
+                // Everything the step reads of its contig is in ONE sector of the record (DevSide) and
+                // is asked for at once: place and length, the 8 bases at this end, the four junction
+                // successors (a forward anchor's distance to the contig's left edge is its offset: whether
+                // this is a hop is known before the sector arrives, and a closing check asks for none) and,
+                // straight after a first hit, the contig's list (see first_hit).
+                const SideVisit at_side = visit<false>(ix, span.anchor, SUCCESSORS && (!forward || span.begin > span.anchor.offset),
+                                                       set.length < 0);
+                if (set.length < 0) map_contig<STATS>(ix, span.anchor, at_side, set, span, &ls);
+                if (span.n == 0) {                            // (a first hit without targets: as map_contig left it)
+                    state = N_MATE_DONE;
                 } else {
-                    span.begin -= shift + 1;
-                    if (span.begin < 0) {
-                        span.begin = 0;
+                    const int move = forward ? span.anchor.offset : at_side.length - span.anchor.offset - K;
+                    if (STATS) ls.contig_reads++;
+                    const bool in_loop = span.begin > move;
+                    int at;
+                    if (in_loop) {
+                        span.begin -= move;
+                        span.anchor.offset -= forward ? move : -move;
+                        at = span.begin;
+                    } else {                                      // closing check, :270-275
+                        span.anchor.offset -= forward ? span.begin : -span.begin;
+                        at = 0;
+                    }
+                    // (the closing check compares read bases 0..7: kept with the context)
+                    const QWindow q = in_loop ? left_window(rv, at) : edge_window(edge & 0xffffu, head_acgt, 0);
+                    const int shift = sift4_left(in_loop ? contig8_edge<STATS>(ix, span.anchor, at_side, true, &ls)
+                                                         : contig8<STATS>(ix, span.anchor, at_side.offset, true, &ls), q, at);
+                    if (!in_loop) {
+                        if (shift == INVALID_SHIFT) span.n = 0;
                         state = N_RIGHT_ENTER;
-                    } else if (SUCCESSORS) {
-                        // the junction lookup (:247-249), answered by the record of the contig the hop
-                        // leaves: what A_LOOKUP does for Y_LJ, without the visit to the k-mer table
-                        span.anchor = junction_successor(next, span.anchor, read_code(rv, span.begin));
-                        if (span.anchor.offset >= 0) state = M_LJ;
-                        else if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }     // :250-259
-                        else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
+                    } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                        span.n = 0;
+                        state = N_AFTER;
                     } else {
-                        kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)          // _kmer.prepend
-                               | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
-                        state = Y_LJ;
+                        span.begin -= shift + 1;
+                        if (span.begin < 0) {
+                            span.begin = 0;
+                            state = N_RIGHT_ENTER;
+                        } else if (SUCCESSORS) {
+                            // the junction lookup (:247-249), answered by the record of the contig the hop
+                            // leaves: what A_LOOKUP does for Y_LJ, without the visit to the k-mer table
+                            uint32_t kind;
+                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.begin), kind);
+                            if (kind == SUCC_LOOKUP) {            // (the k-mer words are needed: the first hit goes)
+                                kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)
+                                       | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
+                                state = Y_LJ;
+                                first_hit_kept = 0;
+                            } else if (kind != SUCC_ABSENT) {
+                                span.anchor = landing;
+                                state = M_LJ;
+                            } else {
+                                span.anchor = invalid_coord();
+                                if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }      // :250-259
+                                else { span.begin -= K; kmer = read_kmer(rv, span.begin); state = Y_LS; first_hit_kept = 0; }
+                            }
+                        } else {
+                            kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)          // _kmer.prepend
+                                   | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
+                            state = Y_LJ;
+                        }
                     }
                 }
             } else if (valid && action == A_RIGHT) {
                 // -------------- _filter_targets_to_right: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
                 const int rest = rv.len - span.end - K;
-                const SuccessorQuad next = load_successors<true>(ix, span.anchor,
-                                                                 SUCCESSORS && (forward || rest > span.anchor.offset));
-                const int move = right_move(ix, span.anchor);
-                if (STATS) ls.contig_reads++;
-                const bool in_loop = rest > move;
-                int at;
-                if (in_loop) {
-                    span.end += move;
-                    span.anchor.offset += forward ? move : -move;
-                    at = span.end + K - ALIGN_LENGTH;
-                } else {                                      // closing check, :335-343
-                    span.anchor.offset += forward ? rest : -rest;
-                    at = rv.len - ALIGN_LENGTH;
-                }
-                // (the closing check compares the last 8 read bases: kept with the context)
-                const QWindow q = in_loop ? right_window(rv, at) : edge_window(edge >> 16, tail_acgt, at);
-                const int shift = sift4_right(in_loop ? contig8_edge<STATS>(ix, span.anchor, false, &ls)
-                                                      : contig8<STATS>(ix, span.anchor, false, &ls), q, at, rv.len);
-                if (!in_loop) {
-                    if (shift == INVALID_SHIFT) span.n = 0;
-                    state = N_AFTER;
-                } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
-                    span.n = 0;
-                    state = N_AFTER;
+                const SideVisit at_side = visit<true>(ix, span.anchor, SUCCESSORS && (forward || rest > span.anchor.offset),
+                                                      set.length < 0);
+                if (set.length < 0) map_contig<STATS>(ix, span.anchor, at_side, set, span, &ls);
+                if (span.n == 0) {                            // (a first hit without targets: as map_contig left it)
+                    state = N_MATE_DONE;
                 } else {
-                    span.end += shift + 1;
-                    if (span.end + K > rv.len) {
-                        span.end = rv.len - K;
+                    const int move = forward ? at_side.length - span.anchor.offset - K : span.anchor.offset;
+                    if (STATS) ls.contig_reads++;
+                    const bool in_loop = rest > move;
+                    int at;
+                    if (in_loop) {
+                        span.end += move;
+                        span.anchor.offset += forward ? move : -move;
+                        at = span.end + K - ALIGN_LENGTH;
+                    } else {                                      // closing check, :335-343
+                        span.anchor.offset += forward ? rest : -rest;
+                        at = rv.len - ALIGN_LENGTH;
+                    }
+                    // (the closing check compares the last 8 read bases: kept with the context)
+                    const QWindow q = in_loop ? right_window(rv, at) : edge_window(edge >> 16, tail_acgt, at);
+                    const int shift = sift4_right(in_loop ? contig8_edge<STATS>(ix, span.anchor, at_side, false, &ls)
+                                                          : contig8<STATS>(ix, span.anchor, at_side.offset, false, &ls),
+                                                  q, at, rv.len);
+                    if (!in_loop) {
+                        if (shift == INVALID_SHIFT) span.n = 0;
                         state = N_AFTER;
-                    } else if (SUCCESSORS) {
-                        // the junction lookup (:309-311) from the record: Y_RJ's part of A_LOOKUP
-                        span.anchor = junction_successor(next, span.anchor, read_code(rv, span.end + K - 1));
-                        if (span.anchor.offset >= 0) state = M_RJ;
-                        else { span.n = 0; state = N_AFTER; }                                    // :312-315
+                    } else if (shift == INVALID_SHIFT || shift + 1 + move <= 0) {
+                        span.n = 0;
+                        state = N_AFTER;
                     } else {
-                        kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)          // _kmer.append
-                                | read_code(rv, span.end + K - 1)) & KMER_MASK;
-                        state = Y_RJ;
+                        span.end += shift + 1;
+                        if (span.end + K > rv.len) {
+                            span.end = rv.len - K;
+                            state = N_AFTER;
+                        } else if (SUCCESSORS) {
+                            // the junction lookup (:309-311) from the record: Y_RJ's part of A_LOOKUP
+                            uint32_t kind;
+                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.end + K - 1), kind);
+                            if (kind == SUCC_LOOKUP) {
+                                kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)
+                                        | read_code(rv, span.end + K - 1)) & KMER_MASK;
+                                state = Y_RJ;
+                            } else if (kind != SUCC_ABSENT) {
+                                span.anchor = landing;
+                                state = M_RJ;
+                            } else {                                                                  // :312-315
+                                span.anchor = invalid_coord();
+                                span.n = 0;
+                                state = N_AFTER;
+                            }
+                        } else {
+                            kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)          // _kmer.append
+                                    | read_code(rv, span.end + K - 1)) & KMER_MASK;
+                            state = Y_RJ;
+                        }
                     }
                 }
             } else if (action == A_EMIT) {
@@ -1315,7 +1362,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                             state = Y_RA;
                         }
                     } else {
-                        state = N_AFTER;
+                        state = set.length < 0 ? M_FIRST : N_AFTER;   // (a first hit no step follows: its list)
                     }
                 } else if (state == N_AFTER) {
                     if (span.n != 0 || attempt == 1) {
@@ -1436,9 +1483,10 @@ void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *bucket
     hipLaunchKernelGGL(probe_check_kernel, dim3(4096), dim3(256), 0, stream, ix, n_slots, report);
 }
 
-void launch_successor_build(const DevIndex &ix, DevContig *records, int64_t n_contigs, hipStream_t stream)
+void launch_successor_build(const DevIndex &ix, DevContig *records, int64_t n_contigs, int force_lookup,
+                            hipStream_t stream)
 {
-    hipLaunchKernelGGL(successor_build_kernel, dim3(2048), dim3(256), 0, stream, ix, records, n_contigs);
+    hipLaunchKernelGGL(successor_build_kernel, dim3(2048), dim3(256), 0, stream, ix, records, n_contigs, force_lookup);
 }
 
 void launch_offsets_scan(int64_t *offsets, int64_t n_reads, int64_t base, unsigned long long *out,

@@ -114,6 +114,27 @@ def test_chr21_adversarial(oracle, native_libs, chr21, chr21_oracle_index, paire
     _compare_tables(oracle, expected, fld, result)
 
 
+@pytest.mark.parametrize('paired', [True, False])
+def test_hops_that_must_look_their_junction_up(oracle, native_libs, chr21, chr21_oracle_index, paired, monkeypatch):
+    """A hop reads map_kmer of its junction k-mer (_mapper.pyx:246-248, :308-310) from the record of
+    the contig it leaves when that k-mer is the first or the last k-mer of its own contig -- true of
+    every junction of a built index -- and looks it up in the table otherwise (SUCC_LOOKUP,
+    skm_device.h).  SKM_TEST_SUCC_LOOKUP=1 marks every successor "look it up" at upload, so the
+    fall-back carries all hops here, including the ones behind a kept first hit."""
+    monkeypatch.setenv('SKM_TEST_SUCC_LOOKUP', '1')
+    rng = np.random.default_rng(7)
+    reads = _adversarial_reads(chr21[1], rng, 6000, 100)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    assert index.device_info()['successors'] == 1
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = len(reads) // 2 if paired else len(reads)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, paired, fld)
+    result, units = _run_gpu(index, bases, offsets, n_units, paired)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_edge_windows_and_pool_fallback(oracle, native_libs, chr21, chr21_oracle_index):
     """A built index takes the 8-base windows at contig ends from first_kmer/last_kmer
     (skm_index_info[6] == 1); an index whose edge k-mers do not spell the pooled bases
