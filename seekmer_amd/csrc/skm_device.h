@@ -88,7 +88,16 @@ static_assert(offsetof(DevSide, targets) == 4 * SIDE_TARGETS_WORD, "the inline t
 // (210 of the ~600 instructions of a lookup), overflowing into the next
 // bucket.  At one k-mer per bucket on average 98 % of the lookups -- hits and
 // misses alike -- end in the bucket they start in: one sector per lookup
-// instead of 1.3, and a miss is known from the first 32 bytes.
+// instead of 1.3, and a miss is known from the first 16 bytes.
+// A k-mer is kept in canonical form (the smaller of itself and its reverse
+// complement: one comparison per entry) with a flag that says the reference's
+// table stores the other strand -- map_kmer complements the entry when the
+// query is the reverse complement of what is STORED (_common.pyx:84-87) --
+// and its 50 bits are split over two words, `low` first for all four entries:
+// 31 bits decide "not this one" for all but one query in 2^31, and a k-mer can
+// never look like a free entry (bit 31).  The first-hit roll, which looks up
+// run after run of k-mers that are not in the table, asks for the 16 bytes of
+// `low` only and fetches the rest for the entry that matches them.
 // skm_index_create builds it on the device from the reference table and only
 // after checking, slot by slot, that the reference's own probe finds every
 // stored k-mer where it is stored (true of any built index); a table that
@@ -96,9 +105,17 @@ static_assert(offsetof(DevSide, targets) == 4 * SIDE_TARGETS_WORD, "the inline t
 // nullptr).  The counting build always probes the reference's layout: its
 // slot counts define the algorithmic bytes.
 struct alignas(64) DevBucket {
+    uint32_t low[4];           // bits 0..30 of the canonical k-mer; BUCKET_FREE = free entry
+    uint32_t high[4];          // bits 31..49; BUCKET_STORED_RC = the table stores its reverse complement
+    Coord pos[4];
+};
+struct alignas(64) DevBucketBuild {   // the same bytes while the table is being filled (64-bit compare-and-swap)
     uint64_t kmer[4];          // KMER_INVALID = free entry
     Coord pos[4];
 };
+constexpr uint32_t BUCKET_FREE = 0xFFFFFFFFu, BUCKET_LOW_MASK = 0x7FFFFFFFu;
+constexpr uint32_t BUCKET_HIGH_MASK = 0x7FFFFu, BUCKET_STORED_RC = 1u << 19;
+static_assert(2 * K == 50, "DevBucket splits a 50-bit k-mer 31 + 19");
 
 // Index as it lives in HBM.  kmers keeps the reference's array layout;
 // contigs are re-packed (above), the pooled contig bases go to 2 bits (32
@@ -250,7 +267,6 @@ __device__ __forceinline__ uint32_t bucket_hash(uint64_t canonical)
     return h * 0xC2B2AE3Du;
 }
 
-typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 // bucket b of the table through a 32-bit byte offset from the (wave-uniform) base where it fits
 __device__ __forceinline__ const DevBucket *bucket_at(const DevIndex &ix, uint32_t b)
 {
@@ -258,28 +274,56 @@ __device__ __forceinline__ const DevBucket *bucket_at(const DevIndex &ix, uint32
 }
 
 // the four k-mers of a bucket (first 32 bytes of its sector)
-struct BucketKeys { u64x2 a, b; };
+struct BucketKeys { u32x4 low, high; };
 __device__ __forceinline__ BucketKeys bucket_keys(const DevIndex &ix, uint32_t b)
 {
-    const u64x2 *p = reinterpret_cast<const u64x2 *>(bucket_at(ix, b));
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(bucket_at(ix, b));
     return BucketKeys{p[0], p[1]};
 }
-
-// Judge one bucket for the query (kmer, rc): 0..3 = entry that holds it (flip set when it is
-// stored as the reverse complement), -1 = not here and the bucket has a free entry (a miss),
-// -2 = not here and the bucket is full (look in the next one).
-__device__ __forceinline__ int bucket_find(const BucketKeys &k, uint64_t kmer, uint64_t rc, bool &flip)
+__device__ __forceinline__ u32x4 bucket_low(const DevIndex &ix, uint32_t b)
 {
-    const uint64_t s[4] = {k.a.x, k.a.y, k.b.x, k.b.y};
-    int found = -2;
+    return *reinterpret_cast<const u32x4 *>(bucket_at(ix, b));
+}
+
+// Judge the `low` words of a bucket for a canonical k-mer: 0..3 = the one entry that can hold it,
+// -1 = not here and the bucket has a free entry (a miss), -2 = not here and the bucket is full (look
+// in the next one), -3 = more than one entry shares the 31 bits (judge the whole keys).
+__device__ __forceinline__ int bucket_screen(const u32x4 &low, uint64_t canonical)
+{
+    const uint32_t want = (uint32_t)canonical & BUCKET_LOW_MASK;
+    const uint32_t s[4] = {low.x, low.y, low.z, low.w};
+    int found = -2, same = 0;
 #pragma unroll
     for (int j = 3; j >= 0; --j) {
-        if (s[j] == KMER_INVALID) found = -1;
+        if (s[j] == BUCKET_FREE) found = -1;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (s[j] == kmer) { found = j; flip = false; }
-        if (s[j] == rc) { found = j; flip = true; }
+        if (s[j] == want) { found = j; ++same; }
+    }
+    return same > 1 ? -3 : found;
+}
+
+// Judge one bucket for the query (kmer, rc): 0..3 = entry that holds it (flip set when the table
+// stores its reverse complement), -1 = not here and the bucket has a free entry (a miss),
+// -2 = not here and the bucket is full (look in the next one).
+__device__ __forceinline__ int bucket_find(const BucketKeys &k, uint64_t kmer, uint64_t rc, bool &flip)
+{
+    const uint64_t canonical = kmer < rc ? kmer : rc;
+    const uint32_t want_low = (uint32_t)canonical & BUCKET_LOW_MASK, want_high = (uint32_t)(canonical >> 31);
+    const uint32_t lo[4] = {k.low.x, k.low.y, k.low.z, k.low.w};
+    const uint32_t hi[4] = {k.high.x, k.high.y, k.high.z, k.high.w};
+    int found = -2;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {
+        if (lo[j] == BUCKET_FREE) found = -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (lo[j] == want_low && (hi[j] & BUCKET_HIGH_MASK) == want_high) {
+            found = j;
+            flip = ((hi[j] & BUCKET_STORED_RC) != 0) != (kmer != canonical);
+        }
     }
     return found;
 }
@@ -309,6 +353,26 @@ __device__ __forceinline__ Coord map_kmer_buckets(const DevIndex &ix, uint64_t k
 {
     bool found;
     return map_kmer_buckets(ix, kmer, found);
+}
+// The same with the home bucket's four positions asked for together with its keys (the whole
+// sector in one go): the position of the entry that matches is then a register select and not a
+// second, dependent access -- for the lookups that expect a hit.
+__device__ __forceinline__ Coord map_kmer_buckets_whole(const DevIndex &ix, uint64_t kmer)
+{
+    const uint64_t rc = kmer_revcomp(kmer);
+    const uint32_t b = bucket_hash(kmer < rc ? kmer : rc) >> ix.bucket_shift;
+    const BucketKeys keys = bucket_keys(ix, b);
+    const u32x4 *p = reinterpret_cast<const u32x4 *>(bucket_at(ix, b)->pos);
+    const u32x4 p01 = p[0], p23 = p[1];
+    bool flip = false;
+    const int j = bucket_find(keys, kmer, rc, flip);
+    if (j >= 0) {
+        const uint32_t entry = j == 0 ? p01.x : j == 1 ? p01.z : j == 2 ? p23.x : p23.z;
+        const uint32_t offset = j == 0 ? p01.y : j == 1 ? p01.w : j == 2 ? p23.y : p23.w;
+        return Coord{(int32_t)(flip ? ~entry : entry), (int32_t)offset};
+    }
+    if (j == -1) return invalid_coord();
+    return map_kmer_buckets(ix, kmer);              // a full bucket: the chain from the start
 }
 
 // The k-mer whose map_kmer result side `side`, successor `b` of a record holds (see DevContig): the

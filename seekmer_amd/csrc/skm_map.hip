@@ -206,7 +206,7 @@ offsets_rebase_kernel(int64_t *offsets, int64_t n, int64_t base)
 
 // ------------------------------------------------- bucket table construction
 __global__ void __launch_bounds__(256)
-bucket_init_kernel(DevBucket *buckets, uint64_t n_buckets)
+bucket_init_kernel(DevBucketBuild *buckets, uint64_t n_buckets)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_buckets * 4;
          i += (uint64_t)gridDim.x * blockDim.x) {
@@ -217,9 +217,10 @@ bucket_init_kernel(DevBucket *buckets, uint64_t n_buckets)
 
 // every occupied slot of the reference table goes into the first free entry from its bucket
 // on; report[0] = entries placed, [1] = placed outside their home bucket, [2] = k-mers met
-// twice (the table is not a set: the caller drops the bucket table)
+// twice or with bits above the 2k a k-mer has (the table is not a set of k-mers: the caller
+// drops the bucket table)
 __global__ void __launch_bounds__(256)
-bucket_fill_kernel(const IndexEntry *__restrict__ kmers, uint64_t n_slots, DevBucket *buckets,
+bucket_fill_kernel(const IndexEntry *__restrict__ kmers, uint64_t n_slots, DevBucketBuild *buckets,
                    uint32_t bucket_mask, uint32_t bucket_shift, unsigned long long *report)
 {
     unsigned long long placed = 0, moved = 0, twice = 0;
@@ -227,6 +228,7 @@ bucket_fill_kernel(const IndexEntry *__restrict__ kmers, uint64_t n_slots, DevBu
          i += (uint64_t)gridDim.x * blockDim.x) {
         const IndexEntry e = kmers[i];
         if (e.kmer == KMER_INVALID) continue;
+        if (e.kmer & ~KMER_MASK) { ++twice; continue; }
         const uint64_t rc = kmer_revcomp(e.kmer);
         const uint32_t home = bucket_hash(e.kmer < rc ? e.kmer : rc) >> bucket_shift;
         uint32_t b = home;
@@ -251,6 +253,29 @@ bucket_fill_kernel(const IndexEntry *__restrict__ kmers, uint64_t n_slots, DevBu
     if (placed) atomicAdd(&report[0], placed);
     if (moved) atomicAdd(&report[1], moved);
     if (twice) atomicAdd(&report[2], twice);
+}
+
+// The filled buckets in the form the mapper reads (DevBucket), in place: a lane per bucket.
+__global__ void __launch_bounds__(256)
+bucket_pack_kernel(DevBucketBuild *buckets, uint64_t n_buckets)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_buckets;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t stored[4];
+        for (int j = 0; j < 4; ++j) stored[j] = buckets[i].kmer[j];
+        DevBucket *packed = reinterpret_cast<DevBucket *>(&buckets[i]);
+        for (int j = 0; j < 4; ++j) {
+            uint32_t low = BUCKET_FREE, high = BUCKET_FREE;
+            if (stored[j] != KMER_INVALID) {
+                const uint64_t rc = kmer_revcomp(stored[j]);
+                const uint64_t canonical = stored[j] < rc ? stored[j] : rc;
+                low = (uint32_t)canonical & BUCKET_LOW_MASK;
+                high = (uint32_t)(canonical >> 31) | (stored[j] != canonical ? BUCKET_STORED_RC : 0u);
+            }
+            packed->low[j] = low;
+            packed->high[j] = high;
+        }
+    }
 }
 
 // The bucket table answers "is this k-mer in the set, and with which position"; the
@@ -723,7 +748,10 @@ enum : int { ST_IDLE = 0, ST_NEW,
              Y_SCAN,                                   // want a run of lookups
              ST_HALF };                                // a mate that is done and waits for the other one
 enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_ACTIONS };
-constexpr int SCAN_ROUNDS = 4;
+#ifndef SKM_SCAN_ROUNDS
+#define SKM_SCAN_ROUNDS 5
+#endif
+constexpr int SCAN_ROUNDS = SKM_SCAN_ROUNDS;    // k-mers one round of the first-hit roll looks up together
 
 
 constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
@@ -746,7 +774,7 @@ __device__ __forceinline__ int action_of(int state)
 template <bool STATS, bool BUCKETS>
 __device__ __forceinline__ Coord lookup_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
 {
-    if (BUCKETS) return map_kmer_buckets(ix, kmer);
+    if (BUCKETS) return map_kmer_buckets_whole(ix, kmer);
     return map_kmer<STATS>(ix, kmer, st);
 }
 
@@ -992,44 +1020,52 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 // independent loads: one memory latency for the lot) and then judged in read
                 // order, so the first hit is the one the reference's one-by-one roll stops at.
                 // A k-mer joins the group while its last base is in the 16-base look-ahead.
-                uint64_t cand[SCAN_ROUNDS];
-                cand[0] = kmer;
-                int m = 1;
+                // Every candidate asks for the 16 bytes of `low` words of its bucket (DevBucket) and keeps
+                // the 31 bits it is looking for: five registers per candidate.  All of them but the last
+                // are expected to miss -- the read is being rolled past a sequencing error -- and a miss
+                // is settled by those words alone; the entry that matches them is fetched whole.
+                uint32_t want[SCAN_ROUNDS];
+                u32x4 low[SCAN_ROUNDS];
+                int m = 0;
+                {
+                    uint64_t rolling = kmer;
 #pragma unroll
-                for (int j = 1; j < SCAN_ROUNDS; ++j) {
-                    const int at = scan_i + j - 1;                 // the base that makes candidate j
-                    const bool ok = m == j && at < rv.len && (at >> 4) == (scan_i >> 4);
-                    cand[j] = ok ? ((cand[j - 1] << 2) | ((look >> (30 - 2 * (at & 15))) & 3u)) & KMER_MASK
-                                 : cand[j - 1];
-                    m += ok ? 1 : 0;
-                }
-                uint64_t rcs[SCAN_ROUNDS];
-                uint32_t home[SCAN_ROUNDS];
-                BucketKeys keys[SCAN_ROUNDS];
-#pragma unroll
-                for (int j = 0; j < SCAN_ROUNDS; ++j) {
-                    rcs[j] = kmer_revcomp(cand[j]);
-                    home[j] = bucket_hash(cand[j] < rcs[j] ? cand[j] : rcs[j]) >> ix.bucket_shift;
-                    keys[j] = bucket_keys(ix, home[j]);            // (j >= m repeats the last one: same sector)
-                }
-                int last = 0;                                      // candidate the roll stopped at
-                Coord pos = invalid_coord();
-#pragma unroll
-                for (int j = 0; j < SCAN_ROUNDS; ++j) {
-                    if (j < m && pos.offset < 0 && last == (j == 0 ? 0 : j - 1)) {
-                        last = j;
-                        kmer = cand[j];
-                        bool flip = false;
-                        const int e = bucket_find(keys[j], cand[j], rcs[j], flip);
-                        pos = invalid_coord();                     // (span.anchor is the LAST lookup's result)
-                        if (e >= 0) {
-                            const Coord c = bucket_at(ix, home[j])->pos[e];
-                            pos = flip ? Coord{~c.entry, c.offset} : c;
-                        } else if (e == -2) {                      // full bucket: the long way round
-                            pos = map_kmer_buckets(ix, cand[j]);
-                        }
-                        // (an occupied slot without a position, offset < 0, is a miss too: :203, :211)
+                    for (int j = 0; j < SCAN_ROUNDS; ++j) {
+                        const int at = scan_i + j - 1;             // the base that makes candidate j
+                        const bool ok = j == 0 || (m == j && at < rv.len && (at >> 4) == (scan_i >> 4));
+                        if (ok && j > 0)
+                            rolling = ((rolling << 2) | ((look >> (30 - 2 * (at & 15))) & 3u)) & KMER_MASK;
+                        m += ok ? 1 : 0;
+                        const uint64_t rc = kmer_revcomp(rolling);
+                        const uint64_t canonical = rolling < rc ? rolling : rc;
+                        want[j] = (uint32_t)canonical;
+                        low[j] = bucket_low(ix, bucket_hash(canonical) >> ix.bucket_shift);   // (j >= m repeats the last one)
                     }
+                }
+                // judged in read order: the roll stops at the first candidate that is not a plain miss
+                // (a likely hit, a full bucket, two entries alike) and looks that one up in full -- its
+                // sector is in the cache.  Should that be a miss after all (or a k-mer stored without a
+                // position, offset < 0: a miss too, :203, :211), the judging goes on behind it.
+                int last = 0;                                      // candidate the roll stopped at
+                Coord pos = invalid_coord();                       // (span.anchor is the LAST lookup's result)
+                const uint64_t first = kmer;
+                for (int from = 0; from < m;) {
+                    int stop = -1;
+#pragma unroll
+                    for (int j = 0; j < SCAN_ROUNDS; ++j) {
+                        if (j >= from && j < m && stop < 0) {
+                            last = j;
+                            if (bucket_screen(low[j], want[j]) != -1) stop = j;
+                        }
+                    }
+                    kmer = first;
+                    for (int r = 0; r < last; ++r)                 // the k-mer of candidate `last`
+                        kmer = ((kmer << 2) | ((look >> (30 - 2 * ((scan_i + r) & 15))) & 3u)) & KMER_MASK;
+                    pos = invalid_coord();
+                    if (stop < 0) break;
+                    pos = map_kmer_buckets(ix, kmer);
+                    if (pos.offset >= 0) break;
+                    from = stop + 1;
                 }
                 scan_i += last;
                 span.anchor = pos;
@@ -1219,27 +1255,32 @@ map_units_kernel(DevIndex ix, MapBatch b)
                     if (b.paired) {
                         // map_read_pair, _mapper.pyx:129-144: both mates' contexts of the pair slot
                         const int c1 = c & ~1, c2 = c | 1;
-                        const int word1 = c_state[c1], word2 = c_state[c2];
-                        Span s1{c_begin[c1], c_end[c1], Coord{c_aentry[c1], c_aoffset[c1]}, (int32_t)((uint32_t)word1 >> 10)};
+                        // (only the lists and their sizes before the intersection: what the fragment
+                        // length needs is read from the contexts behind it -- registers are short here)
+                        Span s1{0, 0, Coord{0, 0}, (int32_t)((uint32_t)c_state[c1] >> 10)};
                         TSet set1{c_tstart[c1], c_tlen[c1] >> 1, (c_tlen[c1] & 1) != 0,
                                   ((uint64_t)c_mask_hi[c1] << 32) | c_mask_lo[c1], ext1, ext_words};
-                        span = Span{c_begin[c2], c_end[c2], Coord{c_aentry[c2], c_aoffset[c2]}, (int32_t)((uint32_t)word2 >> 10)};
+                        span = Span{0, 0, Coord{0, 0}, (int32_t)((uint32_t)c_state[c2] >> 10)};
                         set = TSet{c_tstart[c2], c_tlen[c2] >> 1, (c_tlen[c2] & 1) != 0,
                                    ((uint64_t)c_mask_hi[c2] << 32) | c_mask_lo[c2], ext2, ext_words};
-                        const int len1 = (int)((uint32_t)c_len[c1] & 0xffffffu), len2 = (int)((uint32_t)c_len[c2] & 0xffffffu);
-                        const Span s2 = span;
                         phase(0);
-                        if (!intersect<COUNT>(ix, set1, s1, set, s2)) {
+                        const bool common = intersect<COUNT>(ix, set1, s1, set, span);
+                        s1.begin = c_begin[c1];
+                        s1.end = c_end[c1];
+                        s1.anchor = Coord{c_aentry[c1], c_aoffset[c1]};
+                        const Coord anchor2{c_aentry[c2], c_aoffset[c2]};
+                        if (!common) {
                             s1.n = 0;
                             s1.begin = 0;
                             s1.end = -K;
-                        } else if (s1.anchor.entry != ~s2.anchor.entry) {
+                        } else if (s1.anchor.entry != ~anchor2.entry) {
                             s1.begin = 0;
                             s1.end = -K;
                         } else {
-                            int interval = s2.anchor.offset - s1.anchor.offset;
+                            const int len1 = (int)((uint32_t)c_len[c1] & 0xffffffu), len2 = (int)((uint32_t)c_len[c2] & 0xffffffu);
+                            int interval = anchor2.offset - s1.anchor.offset;
                             if (s1.anchor.entry < 0) interval = -interval;
-                            s1.end = (len1 - K) + interval + (len2 - K) - s2.begin;
+                            s1.end = (len1 - K) + interval + (len2 - K) - c_begin[c2];
                         }
                         span = s1;
                         set = set1;
@@ -1477,9 +1518,11 @@ map_units_kernel(DevIndex ix, MapBatch b)
 void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *buckets, uint32_t bucket_mask,
                          uint32_t bucket_shift, unsigned long long *report, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bucket_init_kernel, dim3(4096), dim3(256), 0, stream, buckets, (uint64_t)bucket_mask + 1);
-    hipLaunchKernelGGL(bucket_fill_kernel, dim3(4096), dim3(256), 0, stream, ix.kmers, n_slots, buckets,
+    DevBucketBuild *filling = reinterpret_cast<DevBucketBuild *>(buckets);
+    hipLaunchKernelGGL(bucket_init_kernel, dim3(4096), dim3(256), 0, stream, filling, (uint64_t)bucket_mask + 1);
+    hipLaunchKernelGGL(bucket_fill_kernel, dim3(4096), dim3(256), 0, stream, ix.kmers, n_slots, filling,
                        bucket_mask, bucket_shift, report);
+    hipLaunchKernelGGL(bucket_pack_kernel, dim3(4096), dim3(256), 0, stream, filling, (uint64_t)bucket_mask + 1);
     hipLaunchKernelGGL(probe_check_kernel, dim3(4096), dim3(256), 0, stream, ix, n_slots, report);
 }
 

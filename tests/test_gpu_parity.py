@@ -259,6 +259,19 @@ def test_table_the_reference_probe_does_not_reach_everywhere(oracle, native_libs
     result, units = _run_gpu(index, bases, offsets, n_units, True)
     _compare_units(expected, units)
     _compare_tables(oracle, expected, fld, result)
+    # the buckets keep 50 bits of a k-mer (skm_device.h: DevBucket): a table with an entry that has
+    # more is not theirs to hold either -- the entry can never be found, as in the reference
+    kmers = chr21_oracle_index.kmers.copy()
+    kmers['kmer'][occupied[::997]] |= np.uint64(1) << np.uint64(55)
+    tampered = oracle.OracleIndex(kmers, chr21_oracle_index.contigs, chr21_oracle_index.sequences,
+                                  chr21_oracle_index.targets, lengths=chr21_oracle_index.lengths)
+    index = make_product_index(tampered, chr21[0])
+    assert index.device_info()['bucketed'] == 0
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(tampered, bases, offsets, n_units, True, fld)
+    result, units = _run_gpu(index, bases, offsets, n_units, True)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
 
 
 def test_quantify_resident_without_classes(oracle, native_libs, chr21, chr21_oracle_index):
