@@ -76,8 +76,9 @@ int skm_device_gather_ceiling(int device, int64_t table_bytes, int blocks, int p
  * copied to HBM (the pooled sequences are re-packed to 2 bits per base); the
  * handle owns device memory only.  Limits (SKM_ERR_ARG beyond them): n_slots a
  * power of two <= 2^31, n_contigs < 2^25, n_targets + 32 n_contigs < 2^30 (the
- * contig records carry their first eight targets and their junction successors:
- * one int32 address space), n_bases < 2^31, at most 2^22 - 1 targets per contig.
+ * contig records -- two 64-byte sides, one per end of the contig -- carry the first
+ * nine targets and the junction successors of that end: one int32 address space),
+ * n_bases < 2^31, at most 2^22 - 1 targets per contig.
  * skm_index_destroy gives up the caller's handle; the device copy is released once
  * every mapper created from it has been destroyed too (in either order). */
 typedef struct skm_index skm_index;
@@ -98,13 +99,15 @@ int skm_index_info(const skm_index *index, int64_t info[8]);
  * or none); the device keeps the same set a second time in 64-byte buckets of four entries
  * under a cheap hash, one sector per lookup.  layout[0]=1 when that copy is in use, 0 when
  * the reference's own layout is probed (a table the reference's probe does not reach
- * everywhere, or one holding a k-mer twice); [1]=buckets [2]=k-mers placed [3]=placed outside
- * their home bucket [4]=k-mers met twice [5]=slots the reference's probe does not reach
+ * everywhere, or one holding a k-mer twice or with bits above 2k); [1]=buckets [2]=k-mers placed
+ * [3]=placed outside their home bucket [4]=k-mers met twice or with such bits [5]=slots the
+ * reference's probe does not reach
  * [6]=1 when every contig record carries its junction successors: the map_kmer results of the
  * eight k-mers a hop of _filter_targets_to_left/right (seekmer/_mapper.pyx:246-248, 308-310) can
  * ask for when it leaves the contig, computed once at upload, so that a hop reads its answer
  * from the record instead of visiting the k-mer table (results identical by construction;
- * off for a table probed in the reference's layout). */
+ * off for a table probed in the reference's layout).  A junction k-mer that is neither the
+ * first nor the last k-mer of its contig -- none in a built index -- is marked "look it up". */
 int skm_index_layout(const skm_index *index, int64_t layout[8]);
 
 /* ------------------------------------------------------------------ mapper
