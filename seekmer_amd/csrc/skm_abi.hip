@@ -2220,13 +2220,20 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
     // memory and an event recorded.  The host stays one chunk ahead: chunk i+1 is already
     // queued when it waits for chunk i's verdict, so the GPU never idles at a check-point
     // (a converged EM turns at most one chunk of launches into no-ops).
+    static const bool unfused_rows = getenv("SKM_EM_UNFUSED") != nullptr;
     auto enqueue_chunk = [&](int slot) -> int {
         for (int64_t i = 0; i < chunk; ++i, ++k) {
             // (the first step of a chunk follows the chunk-end em_decide: already judged)
             launch_em_inner(p, (int)(k & 1), i > 0, k, q->stream);
             if (q->comm) {
-                launch_em_rows(p, (int)(k & 1), q->stream);
-                launch_em_rows_to_acc(p, q->stream);
+                // rows -> this rank's numerators (one launch, or two with SKM_EM_UNFUSED), summed over
+                // the ranks, then the finalize on every rank alike
+                if (unfused_rows) {
+                    launch_em_rows(p, (int)(k & 1), q->stream);
+                    launch_em_rows_to_acc(p, q->stream);
+                } else {
+                    launch_em_rows_acc(p, (int)(k & 1), q->stream);
+                }
                 NCCL_TRY(g_rccl.AllReduce(q->acc.p, q->acc.p, (size_t)q->n_tx, NCCL_FLOAT64, NCCL_SUM,
                                           q->comm, q->stream));
                 launch_em_finalize(p, (int)(k & 1), true, q->stream);
@@ -2236,7 +2243,7 @@ int em_run(skm_quant *q, double rel_tol, double x_floor, int64_t max_iters, int6
                 launch_em_rows(p, (int)(k & 1), q->stream);
                 launch_em_finalize(p, (int)(k & 1), false, q->stream);
             }
-            q->launches += q->comm ? 4 : (p.fused ? 2 : 3);
+            q->launches += q->comm ? (unfused_rows ? 4 : 3) : (p.fused ? 2 : 3);
         }
         launch_em_decide(p, k, q->stream);
         q->launches += 1;

@@ -109,6 +109,9 @@ em_rows_kernel(EmProblem p, int parity)
 // agent-scope atomic stores and loads (write-through / L2-bypassing: the XCDs' L2s are not
 // coherent), the store completed (s_waitcnt) before the arrival is counted.  One launch (5.1 us)
 // and one launch gap less per step; bit for bit em_rows + em_finalize.
+// TO_ACC (several ranks): the transcript's numerator goes to p.acc instead -- em_rows +
+// em_rows_to_acc in one launch -- for the all-reduce that sits in front of em_finalize there.
+template <bool TO_ACC>
 __global__ void __launch_bounds__(256, 8)       // (8 waves per SIMD: the 2048-block grid is resident at once)
 em_rows_finalize_kernel(EmProblem p, int parity)
 {
@@ -175,6 +178,10 @@ em_rows_finalize_kernel(EmProblem p, int parity)
             if (sub == 0) atomicExch(&p.arrivals[t], 0u);             // (for the next step)
         }
         if (sub != 0) continue;
+        if (TO_ACC) {
+            p.acc[t] = a;
+            continue;
+        }
         double v = a / eff / p.n_total;                               // infer.py:158
         if (v != v) v = 0.0;                                          // infer.py:159
         x_new[t] = v;
@@ -190,6 +197,7 @@ em_rows_finalize_kernel(EmProblem p, int parity)
         local_max = o > local_max ? o : local_max;
         flags |= __shfl_xor(flags, d, 64);
     }
+    if (TO_ACC) return;                         // (em_finalize judges the step there)
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_max[wave] = local_max; s_flags[wave] = flags; }
     __syncthreads();
@@ -202,7 +210,7 @@ em_rows_finalize_kernel(EmProblem p, int parity)
     }
 }
 
-// multi-GPU only: rows -> per-transcript numerators for the all-reduce
+// multi-GPU only (the unfused form, SKM_EM_UNFUSED): rows -> per-transcript numerators for the all-reduce
 __global__ void __launch_bounds__(256)
 em_rows_to_acc_kernel(EmProblem p)
 {
@@ -637,7 +645,14 @@ void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream)
 
 void launch_em_rows_finalize(const EmProblem &p, int parity, hipStream_t stream)
 {
-    hipLaunchKernelGGL(em_rows_finalize_kernel, dim3((unsigned)em_final_blocks(p)), dim3(256), 0, stream, p, parity);
+    hipLaunchKernelGGL(em_rows_finalize_kernel<false>, dim3((unsigned)em_final_blocks(p)), dim3(256), 0, stream, p, parity);
+}
+
+void launch_em_rows_acc(const EmProblem &p, int parity, hipStream_t stream)
+{
+    EmProblem fused = p;
+    fused.fused = 1;                            // (the grid of the fused form)
+    hipLaunchKernelGGL(em_rows_finalize_kernel<true>, dim3((unsigned)em_final_blocks(fused)), dim3(256), 0, stream, p, parity);
 }
 
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream)

@@ -173,6 +173,7 @@ void launch_em_inner(const EmProblem &p, int parity, bool judge_previous, int64_
 void launch_em_decide(const EmProblem &p, int64_t steps_done, hipStream_t stream);
 void launch_em_rows(const EmProblem &p, int parity, hipStream_t stream);
 void launch_em_rows_finalize(const EmProblem &p, int parity, hipStream_t stream);
+void launch_em_rows_acc(const EmProblem &p, int parity, hipStream_t stream);   // several ranks: em_rows + em_rows_to_acc
 void launch_em_rows_to_acc(const EmProblem &p, hipStream_t stream);
 void launch_em_finalize(const EmProblem &p, int parity, bool from_acc, hipStream_t stream);
 // out = the result of an EM that latched after ctl[1] steps (x0 if even, x1 if odd)

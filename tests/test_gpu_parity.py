@@ -506,6 +506,27 @@ def test_quantification_through_a_one_rank_communicator(oracle, native_libs, mon
         quant.close()
         np.testing.assert_array_equal(steps_c, steps)
         np.testing.assert_array_equal(through, plain)
+        # The per-step numerators of a rank (rows summed per transcript, one launch:
+        # em_rows_finalize_kernel<TO_ACC>) on a table with a transcript in thousands of classes --
+        # several 512-entry rows, summed by different blocks, added in row order by the last to
+        # arrive -- and with transcripts in no class: the same bits through the communicator.
+        rng = np.random.default_rng(5)
+        n_tx, n_classes = 300, 4000
+        cls = np.repeat(np.arange(n_classes), rng.integers(1, 6, n_classes))
+        tx = rng.integers(1, n_tx - 20, cls.size)
+        tx[rng.random(cls.size) < 0.35] = 7
+        offsets_csr, targets_csr = infer._csr_from_class_map(np.vstack([cls, tx]).astype(np.int64), n_classes)
+        counts = rng.integers(0, 40, n_classes).astype('f8')
+        lengths = rng.uniform(50, 3000, n_tx)
+        start = 1.0 / lengths
+        start /= start.sum()
+        skewed = infer._QuantHandle.from_csr(n_tx, offsets_csr, targets_csr, counts)
+        alone, steps_alone = skewed.em(start, lengths)
+        _native.check(hip.skm_quant_set_comm(skewed.handle, comm))
+        reduced, steps_reduced = skewed.em(start, lengths)
+        skewed.close()
+        assert steps_reduced == steps_alone
+        np.testing.assert_array_equal(reduced, alone)
         # A rank whose shard produced NO class while the sample has aligned units elsewhere:
         # it must still go through the set-up with empty class views and every collective of the EM.
         # One rank cannot reach that state by itself, so a test hook adds "units the other ranks
