@@ -427,6 +427,28 @@ int skm_fastq_prefault_finish(skm_fastq_prefault *handle);
 typedef struct skm_fastq_packed skm_fastq_packed;
 int skm_fastq_packed_open(const char *const *paths, int n_paths, int paired, int n_threads,
                           int64_t chunk_bytes, int want_names, skm_fastq_packed **out);
+/* The same reader over a SHARE of the files, for a sample shared out over ranks
+ * (NativeReadFeeder(shard=...) does this for the two-pass reader; seekmer/common.py:126-197 is one
+ * process): file i is read from byte begin[i] to byte end[i], both starts of lines whose number is
+ * a multiple of four (skm_fastq_locate_line), and the first unit carries the number first_unit --
+ * pieces are numbered as the one-process reader numbers them.  A pair of files must hold the same
+ * number of records in its two ranges. */
+int skm_fastq_packed_open_ranges(const char *const *paths, int n_paths, int paired, int n_threads,
+                                 int64_t chunk_bytes, int want_names, const int64_t *begin,
+                                 const int64_t *end, int64_t first_unit, skm_fastq_packed **out);
+/* Where the lines of a file start, without parsing it: the reference's records are lines 4u .. 4u + 3
+ * of a file whatever they hold, so the place of unit u takes the number of newlines before it.
+ * _count_newlines fills counts[k] for the chunks k = first_chunk, first_chunk + chunk_step, ... of
+ * `chunk_bytes` bytes (n_chunks = ceil(file size / chunk_bytes), SKM_ERR_ARG otherwise; the other
+ * entries are left alone: ranks count a share each and add the tables up), *last_line_open = the
+ * file does not end in a newline (its last line counts all the same).  _locate_line: the byte at
+ * which line `line` (from 0) starts given the counts of ALL chunks -- one chunk is walked --, the
+ * file's size when it has fewer lines; SKM_ERR_STATE when the counts are not this file's. */
+int skm_fastq_count_newlines(const char *path, int64_t chunk_bytes, int64_t first_chunk,
+                             int64_t chunk_step, int n_threads, int64_t *counts, int64_t n_chunks,
+                             int *last_line_open);
+int skm_fastq_locate_line(const char *path, int64_t chunk_bytes, const int64_t *counts,
+                          int64_t n_chunks, int64_t line, int64_t *byte_offset);
 /* where the arrays that cross PCIe live (before the first _next; see skm_fastq_set_allocator) */
 int skm_fastq_packed_set_allocator(skm_fastq_packed *reader, void *(*alloc)(size_t),
                                    void (*release)(void *));

@@ -148,6 +148,11 @@ HOST_SYMBOLS = {
     'skm_fastq_cache_bytes': (ctypes.c_int, [c_i64]),
     'skm_fastq_packed_open': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, c_i64, ctypes.c_int, c_void_pp]),
+    'skm_fastq_packed_open_ranges': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, c_i64, ctypes.c_int, c_i64p, c_i64p, c_i64, c_void_pp]),
+    'skm_fastq_count_newlines': (ctypes.c_int, [ctypes.c_char_p, c_i64, c_i64, c_i64, ctypes.c_int, c_i64p, c_i64,
+                                                ctypes.POINTER(ctypes.c_int)]),
+    'skm_fastq_locate_line': (ctypes.c_int, [ctypes.c_char_p, c_i64, c_i64p, c_i64, c_i64, c_i64p]),
     'skm_fastq_packed_set_allocator': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_packed_next': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PackedReads)]),
     'skm_fastq_packed_stats': (ctypes.c_int, [ctypes.c_void_p, c_i64p]),

@@ -620,9 +620,21 @@ class PackedReadFeeder:
     (skm_fastq_packed_*): the reference's feeders (seekmer/common.py:126-197) for the mapper's own
     input format.  Pieces of a paired sample come as two streams (mate 1 files, mate 2 files), each
     numbered by unit; a piece is valid until the next one is asked for (``copy()`` keeps it).
-    ``eligible(paths)``: plain files only -- compressed inputs go through NativeReadFeeder."""
+    ``eligible(paths)``: plain files only -- compressed inputs go through NativeReadFeeder.
 
-    def __init__(self, paths, paired, threads=0, chunk_bytes=0, pinned=False, want_names=False):
+    ``shard=(rank, world)``: this process reads units [T rank / world, T (rank + 1) / world) of the
+    sample's T units, numbered as one process numbers them.  The reference's records are lines
+    4u .. 4u + 3 of a file whatever they hold, so finding unit u takes the newlines before it: every
+    rank counts the newlines of every world-th 8 MiB chunk of every file, ``sum_over_ranks`` (an
+    all-reduce of an int64 array, e.g. parallel.Ranks.sum_int64) adds the tables up, and each rank
+    walks the one chunk that holds its first line and the one that holds its last
+    (skm_fastq_count_newlines / _locate_line): memchr over 1 / world of the text, which is then
+    parsed once, by the rank that owns it."""
+
+    COUNT_CHUNK = 8 << 20
+
+    def __init__(self, paths, paired, threads=0, chunk_bytes=0, pinned=False, want_names=False, shard=None,
+                 sum_over_ranks=None):
         paths = [pathlib.Path(p) for p in paths]
         if paired and len(paths) % 2 != 0:
             raise ValueError('cannot process odd numbers of pair-ended files')
@@ -632,7 +644,56 @@ class PackedReadFeeder:
         self.chunk_bytes = int(chunk_bytes)
         self.pinned = bool(pinned)
         self.want_names = bool(want_names)
+        self.shard = tuple(shard) if shard is not None and shard[1] > 1 else None
+        self.sum_over_ranks = sum_over_ranks
+        if self.shard is not None and sum_over_ranks is None:
+            raise ValueError('a sharded reader needs the ranks\' sum (sum_over_ranks)')
         self.stats = None
+        self.share = None             # (begin bytes, end bytes, first unit, units) of this rank once located
+
+    def locate_share(self):
+        """Byte ranges of this rank's units in every file and the number of its first unit."""
+        if self.share is not None:
+            return self.share
+        host = _native.host()
+        rank, world = self.shard
+        sizes = [p.stat().st_size for p in self.paths]
+        chunks = [(size + self.COUNT_CHUNK - 1) // self.COUNT_CHUNK for size in sizes]
+        table = numpy.zeros(sum(chunks) + len(self.paths), dtype=numpy.int64)
+        views, at = [], 0
+        for path, n in zip(self.paths, chunks):
+            view = table[at:at + n]
+            open_line = ctypes.c_int(0)
+            _native.check_host(host.skm_fastq_count_newlines(
+                str(path).encode(), self.COUNT_CHUNK, rank, world, max(1, self.threads),
+                _native.ptr(view, _native.c_i64p) if n else None, n, ctypes.byref(open_line)), 'skm_fastq_count_newlines')
+            views.append((at, n, open_line.value))
+            at += n
+        table = self.sum_over_ranks(table)
+        counts = [numpy.ascontiguousarray(table[a:a + n]) for a, n, _ in views]
+        lines = [int(c.sum()) + tail for c, (_, _, tail) in zip(counts, views)]
+        reads = [(n + 2) // 4 for n in lines]          # a line 4u + 1 makes a read (a trailing name line alone does not)
+        step = 2 if self.paired else 1
+        units = [min(reads[f:f + step]) for f in range(0, len(reads), step)]     # zip(file1, file2)
+        total = sum(units)
+        lo, hi = total * rank // world, total * (rank + 1) // world
+        begin = numpy.zeros(len(self.paths), dtype=numpy.int64)
+        end = numpy.zeros(len(self.paths), dtype=numpy.int64)
+        first = 0
+        for pair, n_units in enumerate(units):
+            a = min(max(lo - first, 0), n_units)
+            b = min(max(hi - first, 0), n_units)
+            for f in range(pair * step, pair * step + step):
+                for line, out in ((4 * a, begin), (4 * b, end)):
+                    where = ctypes.c_int64()
+                    _native.check_host(host.skm_fastq_locate_line(
+                        str(self.paths[f]).encode(), self.COUNT_CHUNK,
+                        _native.ptr(counts[f], _native.c_i64p) if counts[f].size else None, counts[f].size, line,
+                        ctypes.byref(where)), 'skm_fastq_locate_line')
+                    out[f] = where.value
+            first += n_units
+        self.share = (begin, end, lo, hi - lo)
+        return self.share
 
     @staticmethod
     def eligible(paths):
@@ -663,9 +724,16 @@ class _PackedReader:
         names = [str(p).encode() for p in feeder.paths]
         array = (ctypes.c_char_p * len(names))(*names)
         self.handle = ctypes.c_void_p()
-        _native.check_host(host.skm_fastq_packed_open(
-            array, len(names), int(feeder.paired), feeder.threads, feeder.chunk_bytes, int(feeder.want_names),
-            ctypes.byref(self.handle)), 'skm_fastq_packed_open')
+        if feeder.shard is None:
+            _native.check_host(host.skm_fastq_packed_open(
+                array, len(names), int(feeder.paired), feeder.threads, feeder.chunk_bytes, int(feeder.want_names),
+                ctypes.byref(self.handle)), 'skm_fastq_packed_open')
+        else:
+            begin, end, first_unit, _ = feeder.locate_share()
+            _native.check_host(host.skm_fastq_packed_open_ranges(
+                array, len(names), int(feeder.paired), feeder.threads, feeder.chunk_bytes, int(feeder.want_names),
+                _native.ptr(begin, _native.c_i64p), _native.ptr(end, _native.c_i64p), first_unit,
+                ctypes.byref(self.handle)), 'skm_fastq_packed_open_ranges')
         if feeder.pinned:
             hip = _native.hip()
             _native.check_host(host.skm_fastq_packed_set_allocator(

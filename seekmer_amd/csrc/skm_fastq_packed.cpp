@@ -146,6 +146,7 @@ struct skm_fastq_packed {
     int variant = 0;
     walk_fn walk = walk_scalar;
     std::vector<Mapped> files;
+    std::vector<size_t> file_begin, file_end;  // the bytes of every file this reader covers (a rank's share; else all)
     struct Item { int file, stream; size_t a, b; };          // file < 0: the end of a pair of files
     std::vector<Item> items;
     struct Result { PackedOut *out = nullptr; size_t start = 0, end = 0; bool has_start = false, broken = false; };
@@ -175,7 +176,7 @@ struct skm_fastq_packed {
         if (!r.out) return r;
         const size_t before = r.out->bytes();
         r.out->start(cw_hint.load(std::memory_order_relaxed), want_names && it.stream == 0);
-        if (it.a == 0) { r.has_start = true; r.start = 0; }
+        if (it.a == file_begin[(size_t)it.file]) { r.has_start = true; r.start = it.a; }   // (proven: byte 0, or a share's first record)
         else r.has_start = guess_start(f.p, f.n, it.a, it.b, &r.start);
         if (r.has_start) r.end = walk(f.p, f.n, r.start, it.b, *r.out);
         if (trace)
@@ -242,8 +243,28 @@ extern "C" int skm_pack_set_variant(int variant)
     return SKM_OK;
 }
 
+namespace {
+int open_reader(const char *const *paths, int n_paths, int paired, int n_threads, int64_t chunk_bytes, int want_names,
+                const int64_t *begin, const int64_t *end, int64_t first_unit, skm_fastq_packed **out);
+}
+
 extern "C" int skm_fastq_packed_open(const char *const *paths, int n_paths, int paired, int n_threads,
                                      int64_t chunk_bytes, int want_names, skm_fastq_packed **out)
+{
+    return open_reader(paths, n_paths, paired, n_threads, chunk_bytes, want_names, nullptr, nullptr, 0, out);
+}
+
+extern "C" int skm_fastq_packed_open_ranges(const char *const *paths, int n_paths, int paired, int n_threads,
+                                            int64_t chunk_bytes, int want_names, const int64_t *begin,
+                                            const int64_t *end, int64_t first_unit, skm_fastq_packed **out)
+{
+    if (!begin || !end || first_unit < 0) return SKM_ERR_ARG;
+    return open_reader(paths, n_paths, paired, n_threads, chunk_bytes, want_names, begin, end, first_unit, out);
+}
+
+namespace {
+int open_reader(const char *const *paths, int n_paths, int paired, int n_threads, int64_t chunk_bytes, int want_names,
+                const int64_t *begin, const int64_t *end, int64_t first_unit, skm_fastq_packed **out)
 {
     if (!paths || n_paths <= 0 || !out || n_threads < 0 || chunk_bytes < 0) return SKM_ERR_ARG;
     if (paired && (n_paths % 2) != 0) return SKM_ERR_ARG;      // common.py:178-179 raises ValueError
@@ -260,22 +281,104 @@ extern "C" int skm_fastq_packed_open(const char *const *paths, int n_paths, int 
     q->files.resize(q->paths.size());
     for (size_t i = 0; i < q->paths.size(); ++i)
         if (!q->files[i].map(q->paths[i].c_str())) { delete q; return SKM_ERR_IO; }
-    q->file_pos.assign(q->files.size(), 0);
+    // the bytes to read: whole files, or the share the caller has located (record boundaries both,
+    // skm_fastq_locate_line) -- a walk that starts at a share's first byte is proven as one from byte 0 is
+    q->file_begin.assign(q->files.size(), 0);
+    q->file_end.resize(q->files.size());
+    for (size_t i = 0; i < q->files.size(); ++i) {
+        q->file_end[i] = q->files[i].n;
+        if (begin) {
+            if (begin[i] < 0 || end[i] < begin[i] || (size_t)end[i] > q->files[i].n) { delete q; return SKM_ERR_ARG; }
+            q->file_begin[i] = (size_t)begin[i];
+            q->file_end[i] = (size_t)end[i];
+        }
+    }
+    q->file_pos = q->file_begin;
     q->file_reads.assign(q->files.size(), 0);
+    q->pair_base = first_unit;
+    q->stream_next[0] = q->stream_next[1] = first_unit;
     const size_t step = q->paired ? 2 : 1;
     for (size_t f = 0; f + step <= q->files.size(); f += step) {
         size_t chunks[2] = {0, 0};
-        for (size_t s = 0; s < step; ++s) chunks[s] = (q->files[f + s].n + q->chunk_bytes - 1) / q->chunk_bytes;
+        for (size_t s = 0; s < step; ++s)
+            chunks[s] = (q->file_end[f + s] - q->file_begin[f + s] + q->chunk_bytes - 1) / q->chunk_bytes;
         for (size_t k = 0; k < std::max(chunks[0], chunks[1]); ++k)
             for (size_t s = 0; s < step; ++s)
                 if (k < chunks[s]) {
-                    const size_t n = q->files[f + s].n;
-                    q->items.push_back({(int)(f + s), (int)s, k * q->chunk_bytes, std::min(n, (k + 1) * q->chunk_bytes)});
+                    const size_t a = q->file_begin[f + s], b = q->file_end[f + s];
+                    q->items.push_back({(int)(f + s), (int)s, a + k * q->chunk_bytes, std::min(b, a + (k + 1) * q->chunk_bytes)});
                 }
         q->items.push_back({-1, (int)f, 0, 0});
     }
     *out = q;
     return SKM_OK;
+}
+}  // namespace
+
+// ---- a sample shared out over ranks ------------------------------------------------------------
+// The reference numbers the LINES of a file (seekmer/common.py:126-197): record u is lines 4u .. 4u + 3
+// whatever they hold.  A rank that reads units [lo, hi) of a sample must therefore know where line
+// 4 lo starts, which takes the number of newlines before it: every rank counts the newlines of its
+// share of fixed-size chunks (skm_fastq_count_newlines; the counts are summed over the ranks by the
+// caller), then finds the chunk that holds the line it wants and walks that one chunk
+// (skm_fastq_locate_line).  memchr over 1/N of the text and over one chunk: the text is parsed once,
+// by the rank that owns it.
+extern "C" int skm_fastq_count_newlines(const char *path, int64_t chunk_bytes, int64_t first_chunk, int64_t chunk_step,
+                                        int n_threads, int64_t *counts, int64_t n_chunks, int *last_line_open)
+{
+    if (!path || chunk_bytes <= 0 || first_chunk < 0 || chunk_step <= 0 || !counts || n_chunks < 0) return SKM_ERR_ARG;
+    Mapped f;
+    if (!f.map(path)) return SKM_ERR_IO;
+    const int64_t have = (int64_t)((f.n + (size_t)chunk_bytes - 1) / (size_t)chunk_bytes);
+    if (have != n_chunks) { f.unmap(); return SKM_ERR_ARG; }
+    if (last_line_open) *last_line_open = f.n > 0 && f.p[f.n - 1] != '\n';
+    std::atomic<int64_t> next{first_chunk};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t k = next.fetch_add(chunk_step);
+            if (k >= n_chunks) return;
+            const size_t a = (size_t)k * (size_t)chunk_bytes, b = std::min(f.n, a + (size_t)chunk_bytes);
+            int64_t c = 0;
+            for (size_t at = a; at < b;) {
+                const char *nl = (const char *)memchr(f.p + at, '\n', b - at);
+                if (!nl) break;
+                ++c;
+                at = (size_t)(nl - f.p) + 1;
+            }
+            counts[k] = c;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < std::max(1, n_threads); ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    f.unmap();
+    return SKM_OK;
+}
+
+// byte at which line `line` (numbered from 0) starts, from the newline counts of ALL chunks; the file's
+// size when the file has fewer lines
+extern "C" int skm_fastq_locate_line(const char *path, int64_t chunk_bytes, const int64_t *counts, int64_t n_chunks,
+                                     int64_t line, int64_t *byte_offset)
+{
+    if (!path || chunk_bytes <= 0 || !counts || n_chunks < 0 || line < 0 || !byte_offset) return SKM_ERR_ARG;
+    if (line == 0) { *byte_offset = 0; return SKM_OK; }
+    Mapped f;
+    if (!f.map(path)) return SKM_ERR_IO;
+    auto done = [&](int rc) { f.unmap(); return rc; };
+    if ((int64_t)((f.n + (size_t)chunk_bytes - 1) / (size_t)chunk_bytes) != n_chunks) return done(SKM_ERR_ARG);
+    int64_t before = 0, k = 0;                     // line `line` starts behind newline number `line` (counted from 1)
+    while (k < n_chunks && before + counts[k] < line) before += counts[k++];
+    if (k >= n_chunks) { *byte_offset = (int64_t)f.n; return done(SKM_OK); }
+    size_t at = (size_t)k * (size_t)chunk_bytes;
+    const size_t b = std::min(f.n, at + (size_t)chunk_bytes);
+    for (int64_t seen = before; at < b;) {
+        const char *nl = (const char *)memchr(f.p + at, '\n', b - at);
+        if (!nl) break;
+        at = (size_t)(nl - f.p) + 1;
+        if (++seen == line) { *byte_offset = (int64_t)at; return done(SKM_OK); }
+    }
+    return done(SKM_ERR_STATE);                    // the counts are not this file's
 }
 
 extern "C" int skm_fastq_packed_set_allocator(skm_fastq_packed *q, void *(*alloc)(size_t), void (*release)(void *))
@@ -417,10 +520,11 @@ extern "C" int skm_fastq_packed_estimate(const skm_fastq_packed *q, int64_t *uni
     const size_t step = q->paired ? 2 : 1;
     for (size_t f = 0; f < q->files.size(); f += step) {
         const Mapped &m = q->files[f];
-        size_t at = 0;
-        for (int line = 0; line < 4 && at < m.n; ++line) at = next_newline(m.p, m.n, at) + 1;
-        if (at > m.n) at = m.n;
-        if (at) total += (int64_t)((m.n + at - 1) / at);
+        const size_t from = q->file_begin[f], to = q->file_end[f];
+        size_t at = from;
+        for (int line = 0; line < 4 && at < to; ++line) at = next_newline(m.p, m.n, at) + 1;
+        if (at > to) at = to;
+        if (at > from) total += (int64_t)((to - from + (at - from) - 1) / (at - from));
     }
     *units = total;
     return SKM_OK;

@@ -65,9 +65,13 @@ def _run(ranks, start_time, index_path, output_path, fastq_paths, job_count, sav
     # (the readers' threads page-lock against THIS GPU; their arena is page-locked by a helper thread
     # from here on, under the index load and upload)
     _native.check(_native.hip().skm_pinned_set_device(device))
-    read_feeder = _feeder(fastq_paths, not single_ended, parse_threads, ranks.shard, save_readmap)
+    read_feeder = _feeder(fastq_paths, not single_ended, parse_threads, ranks.shard, save_readmap,
+                          sum_over_ranks=ranks.sum_int64)
+    one_pass = isinstance(read_feeder, common.PackedReadFeeder)
+    if one_pass and ranks.world > 1:
+        read_feeder.locate_share()          # (a collective: every rank counts its share of the newlines, here)
     # (the one-pass reader maps the text: its page tables are set up by helper threads while the index loads)
-    ahead = common.Prefault(fastq_paths if isinstance(read_feeder, common.PackedReadFeeder) else [], threads=4)
+    ahead = common.Prefault(fastq_paths if one_pass and ranks.world == 1 else [], threads=4)
     try:
         index = common.KMerIndex.load(index_path)
         index.device_handle(device)
@@ -112,16 +116,17 @@ def _check_resample_limit(map_result, ranks):
                          % (RESAMPLE_LIMIT, aligned))
 
 
-def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches):
+def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches, sum_over_ranks=None):
     """The native readers as run() uses them.
 
-    Plain files on one GPU: the one-pass reader (common.PackedReadFeeder) -- the text is parsed
-    straight to the mapper's 2-bit read codes by `parse_threads` workers (None = up to 16, the cores
-    this process may use less one) and drained into the mapper natively; a third of the bytes of the
-    ASCII batches cross PCIe.  Compressed inputs, several ranks (every rank takes every world-th
-    batch of the sample, which needs the line index of the two-pass reader) and `-m` (readmap.txt is
-    written batch by batch in the reference's batches of 65 536, seekmer/common.py:17) go through
-    common.NativeReadFeeder: plain files parsed by up to 8 threads, into page-locked slabs when
+    Plain files: the one-pass reader (common.PackedReadFeeder) -- the text is parsed straight to the
+    mapper's 2-bit read codes by `parse_threads` workers (None = up to 16, the cores this process may
+    use less one) and drained into the mapper natively; a third of the bytes of the ASCII batches
+    cross PCIe.  Several ranks: each reads a contiguous run of the sample's units, found from
+    newline counts that the ranks add up (`sum_over_ranks`; PackedReadFeeder.locate_share).
+    Compressed inputs (every rank then takes every world-th batch of the sample off the two-pass
+    reader's line index) and `-m` (readmap.txt is written batch by batch in the reference's batches
+    of 65 536, seekmer/common.py:17) go through common.NativeReadFeeder: plain files parsed by up to 8 threads, into page-locked slabs when
     there is enough text (> 4 GiB) to pay for pinning them, in batches of 2^18 units (2^20 above
     16 GiB of text); parse_threads 0 = its sequential engine."""
     import os
@@ -133,9 +138,12 @@ def _feeder(fastq_paths, paired, parse_threads, shard, keep_reference_batches):
         except OSError:
             pass
     one_rank = shard is None or shard[1] <= 1
-    if one_rank and not keep_reference_batches and parse_threads != 0 and common.PackedReadFeeder.eligible(fastq_paths):
+    if (one_rank or sum_over_ranks is not None) and not keep_reference_batches and parse_threads != 0 \
+            and common.PackedReadFeeder.eligible(fastq_paths):
         threads = parse_threads if parse_threads else max(1, min(16, cores - 1))
-        return common.PackedReadFeeder(fastq_paths, paired, threads=threads, pinned=total > (1 << 30))
+        world = 1 if one_rank else shard[1]
+        return common.PackedReadFeeder(fastq_paths, paired, threads=threads, pinned=total > (1 << 30) * world,
+                                       shard=None if one_rank else shard, sum_over_ranks=sum_over_ranks)
     if parse_threads is None:
         parse_threads = 0 if keep_reference_batches else min(8, cores)
     if parse_threads <= 0:

@@ -132,6 +132,16 @@ class Ranks:
             out[name] = array
         return out
 
+    def sum_int64(self, array):
+        """The element-wise sum of every rank's int64 array, on every rank (an all-reduce on the host)."""
+        array = numpy.ascontiguousarray(array, dtype=numpy.int64)
+        if self.dist is None or array.size == 0:
+            return array
+        import torch
+        total = torch.from_numpy(array.copy())
+        self.dist.all_reduce(total)
+        return total.numpy()
+
     def fail(self, error):
         """A rank that cannot go on must not leave its peers waiting in a barrier, a gather or an
         RCCL all-reduce: report, and end THIS process with a non-zero status at once (the launcher

@@ -483,8 +483,9 @@ def test_sharded_feeders_partition_the_sample(native_libs, tmp_path, threads):
 
 
 def test_infer_chooses_its_reader(tmp_path):
-    """infer._feeder: plain files on one rank go through the one-pass packed reader; compressed input,
-    -m (readmap.txt in the reference's batches) and a rank's share of a sample keep the ASCII reader."""
+    """infer._feeder: plain files go through the one-pass packed reader (a rank of several: over its
+    share of the sample, given the ranks' all-reduce); compressed input and -m (readmap.txt in the
+    reference's batches) keep the ASCII reader."""
     import gzip
     from seekmer_amd import common, infer
     plain = [tmp_path / 'a_1.fastq', tmp_path / 'a_2.fastq']
@@ -497,7 +498,9 @@ def test_infer_chooses_its_reader(tmp_path):
     assert isinstance(chosen, common.PackedReadFeeder) and chosen.paired and 1 <= chosen.threads <= 16
     assert isinstance(infer._feeder(plain, True, 3, (0, 1), False), common.PackedReadFeeder)
     assert isinstance(infer._feeder(plain, True, None, None, True), common.NativeReadFeeder)       # -m
-    assert isinstance(infer._feeder(plain, True, None, (1, 2), False), common.NativeReadFeeder)    # a rank of two
+    assert isinstance(infer._feeder(plain, True, None, (1, 2), False), common.NativeReadFeeder)    # a rank of two, no exchange
+    shared = infer._feeder(plain, True, None, (1, 2), False, sum_over_ranks=lambda table: table)     # ... with one
+    assert isinstance(shared, common.PackedReadFeeder) and shared.shard == (1, 2)
     assert isinstance(infer._feeder([packed, plain[1]], True, None, None, False), common.NativeReadFeeder)
     assert isinstance(infer._feeder(plain, True, 0, None, False), common.NativeReadFeeder)         # --parse-threads 0
     assert common.PackedReadFeeder.eligible(plain) and not common.PackedReadFeeder.eligible([packed])

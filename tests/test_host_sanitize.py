@@ -73,6 +73,33 @@ for variant in (0, 1, 2):
                 assert streams[s][u] == (want.codes[0, :w].tolist(), len(read),
                                          wexc[1][0][:w].tolist() if wexc[0].size else None), (variant, threads, u, s)
 _native.host().skm_pack_set_variant(-1)
+# a sample shared out over three ranks (newline counts per rank, added up, then each rank's byte ranges):
+# the ranks' pieces together are the reads above under the same unit numbers
+world, tables = 3, []
+class Collect(Exception):
+    pass
+def capture(table):
+    tables.append(table.copy())
+    raise Collect()
+for rank in range(world):
+    feeder = common.PackedReadFeeder(paths, True, threads=2, shard=(rank, world), sum_over_ranks=capture)
+    feeder.COUNT_CHUNK = 4096
+    try:
+        feeder.locate_share()
+    except Collect:
+        pass
+total = sum(tables)
+seen = [dict(), dict()]
+for rank in range(world):
+    feeder = common.PackedReadFeeder(paths, True, threads=2, chunk_bytes=3000, shard=(rank, world), sum_over_ranks=lambda t: total)
+    feeder.COUNT_CHUNK = 4096
+    for piece in feeder:
+        assert not piece.is_cut
+        for r in range(piece.n_reads):
+            assert piece.first_read + r not in seen[piece.stream]
+            seen[piece.stream][piece.first_read + r] = int(piece.lengths[r])
+assert all(sorted(seen[s]) == list(range(2278)) for s in range(2))
+assert all(seen[s][u] == len(flat_reads[2 * u + s]) for s in range(2) for u in range(2278))
 ids, seqs = index_builder.read_transcripts(os.path.join(%(golden)r, 'human.cdna.21.with_extra.fa.gz'))
 index = index_builder.build(ids, seqs)
 assert index.contigs.size == 5

@@ -189,6 +189,20 @@ def _worker(rank, world, port, tmp, queue):
                        'export': result.export(), 'tpm': tpm, 'steps': quantify.steps, 'boots': np.asarray(boots)})
         else:
             assert summarized is None and boots == []
+        # the one-pass packed reader over this rank's share of the sample (what infer.run opens for
+        # plain files on several ranks): the newline counts are added up through the process group
+        import test_packed_reads as packed
+        feeder = infer._feeder(paths, True, 2, ranks.shard, False, sum_over_ranks=ranks.sum_int64)
+        assert isinstance(feeder, common.PackedReadFeeder) and feeder.shard == (rank, world)
+        pieces = [p.copy() for p in feeder]
+        begin, end, first, count = feeder.share
+        assert (first, count) == (N_UNITS * rank // world, N_UNITS * (rank + 1) // world - N_UNITS * rank // world)
+        streams, ends, _ = packed.assemble(pieces, 2)
+        pairs = O.read_fastq_pairs(*paths)
+        for s in range(2):
+            assert sorted(streams[s]) == list(range(first, first + count))
+            for u in range(first, first + count, 37):
+                assert streams[s][u] == packed.expected_packing(pairs[2 * u + s])
     finally:
         ranks.close()
 

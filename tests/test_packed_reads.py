@@ -239,3 +239,101 @@ def test_pack_reads_of_arrays():
     code = _native.host().skm_pack_reads(b'A' * 40, _native.ptr(offsets, _native.c_i64p), 1, 1, codes.ctypes.data,
                                         lengths.ctypes.data, None, None, 0, ctypes.byref(n_exc), -1)
     assert code == _native.SKM_ERR_ARG
+
+
+class _ThreadRanks:
+    """An all-reduce among `world` threads of one process, standing in for the process group."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.lock = threading.Lock()
+        self.total = None
+
+    def sum_int64(self, table):
+        with self.lock:
+            self.total = table.copy() if self.total is None else self.total + table
+        self.barrier.wait()
+        out = self.total.copy()
+        if self.barrier.wait() == 0:
+            self.total = None
+        self.barrier.wait()
+        return out
+
+
+def read_shares(paths, paired, world, threads, chunk_bytes, count_chunk):
+    """Every rank's pieces of a sample shared out over `world` ranks, and every rank's share."""
+    import threading
+    ranks = _ThreadRanks(world)
+    pieces, shares, errors = [None] * world, [None] * world, []
+
+    def one(rank):
+        try:
+            feeder = common.PackedReadFeeder(paths, paired, threads=threads, chunk_bytes=chunk_bytes, want_names=True,
+                                             shard=(rank, world), sum_over_ranks=ranks.sum_int64)
+            feeder.COUNT_CHUNK = count_chunk
+            pieces[rank] = [p.copy_with_names() for p in feeder]
+            shares[rank] = feeder.share
+        except BaseException as error:          # (a rank that fails must not leave the others at the barrier)
+            errors.append(error)
+            ranks.barrier.abort()
+
+    workers = [threading.Thread(target=one, args=(rank,)) for rank in range(world)]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    if errors:
+        raise errors[0]
+    return pieces, shares
+
+
+@pytest.mark.parametrize('kind', ['plain', 'ragged', 'dirty', 'crlf'])
+def test_a_sample_shared_out_over_ranks(tmp_path, kind):
+    """PackedReadFeeder(shard=(rank, world)): every rank finds units [T r / N, T (r + 1) / N) of the
+    sample from newline counts alone (the reference's records are lines 4u .. 4u + 3 whatever they
+    hold, seekmer/common.py:126-197) and reads them in one pass; together the ranks deliver the
+    one-process reader's reads under the one-process reader's unit numbers -- for files of unequal
+    record counts and byte sizes, several pairs of files, a last line without a newline, and more
+    ranks than chunks or than units."""
+    rng = random.Random(hash(kind) & 0xffff)
+    sizes = [(530, 530), (211, 260), (97, 40)]            # records in (mate 1, mate 2) of each pair of files
+    paths = []
+    for k, (n1, n2) in enumerate(sizes):
+        for mate, n in ((1, n1), (2, n2)):
+            text = make_fastq(rng, n, kind)
+            if k == 1 and mate == 1:
+                text = text.rstrip(b'\r\n')                # the last line stays open
+            if k == 2 and mate == 2:
+                text += b'@name without bases\n'           # a trailing name line: no read
+            path = tmp_path / ('s%d_%d.fastq' % (k, mate))
+            path.write_bytes(text)
+            paths.append(path)
+    for paired, files in ((True, paths), (False, paths[::2])):
+        n_streams = 2 if paired else 1
+        ref_names, ref_reads = reference_reads(files, paired)
+        n_units = len(ref_reads) // n_streams
+        for world, threads, chunk_bytes, count_chunk in ((2, 2, 4096, 8192), (3, 0, 1000, 700), (7, 3, 512, 3000),
+                                                         (5, 1, 1 << 20, 1 << 20)):
+            pieces, shares = read_shares(files, paired, world, threads, chunk_bytes, count_chunk)
+            at = 0
+            for rank in range(world):
+                begin, end, first, count = shares[rank]
+                assert first == at == n_units * rank // world and count == n_units * (rank + 1) // world - first
+                streams, ends, names = assemble(pieces[rank], n_streams)
+                assert all(not p.is_cut for p in pieces[rank])          # (the shares end where the shorter file does)
+                for s in range(n_streams):
+                    assert sorted(streams[s]) == list(range(first, first + count)), (rank, s)
+                    for u in range(first, first + count):
+                        assert streams[s][u] == expected_packing(ref_reads[n_streams * u + s]), (u, s)
+                for u in range(first, first + count):
+                    assert names[u] == ref_names[u]
+                at += count
+            assert at == n_units
+    # more ranks than units: the empty shares are empty, the others as above
+    tiny = tmp_path / 'tiny.fastq'
+    tiny.write_bytes(make_fastq(rng, 3, kind))
+    pieces, shares = read_shares([tiny], False, 5, 1, 4096, 64)
+    assert [s[3] for s in shares] == [0, 1, 0, 1, 1]
+    assert sum(p.n_reads for rank in pieces for p in rank) == 3
