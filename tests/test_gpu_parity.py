@@ -1560,6 +1560,64 @@ def test_pairs_of_files_of_unequal_length_and_a_pusher_at_the_byte_limit(oracle,
     _compare_tables(oracle, expected, fld, limited)
 
 
+def test_shares_of_a_sample_through_the_packed_reader(oracle, native_libs, chr21, chr21_oracle_index, tmp_path):
+    """What several ranks do with plain FASTQ files, on one GPU: every "rank" (a thread here, the
+    all-reduce a barrier) reads its run of the sample's units through the one-pass packed reader
+    (PackedReadFeeder(shard=...), skm_fastq_packed_open_ranges) into a mapper of its own, natively
+    drained; the tables merged on the device are the oracle's table of the whole sample -- first-seen
+    order included, i.e. the pieces carried the unit numbers of a one-process run.  Pairs of files of
+    unequal length, 3 ranks."""
+    import test_packed_reads as packed
+    from seekmer_amd import common, mapper
+    rng = np.random.default_rng(77)
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    reads = _adversarial_reads(chr21[1], rng, 2 * 5000, 100)
+    sizes = [(2100, 2300), (1900, 1500)]
+    files, kept, at = [], [], 0
+    for k, (n1, n2) in enumerate(sizes):
+        for s, n in enumerate((n1, n2)):
+            path = tmp_path / ('q%d_%d.fastq' % (k, s + 1))
+            with open(path, 'wb') as f:
+                for u in range(n):
+                    read = reads[2 * (at + u) + s]
+                    f.write(b'@r%d\n' % u + read + b'\n+\n' + b'I' * len(read) + b'\n')
+            files.append(path)
+        for u in range(min(n1, n2)):
+            kept += [reads[2 * (at + u)], reads[2 * (at + u) + 1]]
+        at += max(n1, n2)
+    n_units = len(kept) // 2
+    bases, offsets = oracle.pack_reads(kept)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, n_units, True, fld)
+    world = 3
+    ranks = packed._ThreadRanks(world)
+    feeders = [common.PackedReadFeeder(files, True, threads=2, chunk_bytes=30_000, shard=(r, world),
+                                       sum_over_ranks=ranks.sum_int64) for r in range(world)]
+    import threading
+    failures = []
+
+    def locate(feeder):
+        try:
+            feeder.COUNT_CHUNK = 50_000
+            feeder.locate_share()
+        except BaseException as error:
+            failures.append(error)
+            ranks.barrier.abort()
+
+    workers = [threading.Thread(target=locate, args=(f,)) for f in feeders]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    assert not failures, failures
+    assert [f.share[2] for f in feeders] == [n_units * r // world for r in range(world)]
+    shares = [mapper.map_reads(index, f, job_count=1) for f in feeders]
+    assert [s.sizes()[3] for s in shares] == [f.share[3] for f in feeders]
+    for other in shares[1:]:
+        shares[0].merge_resident(other)
+    _compare_tables(oracle, expected, fld, shares[0])
+
+
 def test_tables_merge_on_the_device(oracle, native_libs, chr21, chr21_oracle_index):
     """SURVEY 8(e).1 without the host: a mapper's class table where it lies in HBM
     (skm_mapper_device_table: registry order, counts as doubles, the arena) merged into another
