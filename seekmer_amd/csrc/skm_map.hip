@@ -57,32 +57,44 @@ __device__ __forceinline__ void pack_dword(uint32_t w, int first, int n, uint64_
 }
 
 // The same four bases when they are expected to be upper-case ACGT (nearly every word of a
-// FASTQ file): codes only, and `bad` collects anything that is not -- a word with bad == 0 has
-// the all-ones flag pattern and needs no more work; any other word is redone by pack_dword.
-__device__ __forceinline__ void pack_dword_plain(uint32_t w, int first, int n, uint64_t &codes, uint32_t &bad)
+// FASTQ file): the byte of their four codes in the TOP byte of the result, and `bad` collects
+// anything that is not such a letter -- a word with bad == 0 has the all-ones flag pattern and
+// needs no more work; any other word is redone by pack_dword.  No count: the caller cuts the
+// word to the read's length afterwards (what lies behind the read's end in the 32 bytes are the
+// next read's bases; should THEY hold something else, the word takes the exact path for nothing).
+__device__ __forceinline__ uint32_t pack_dword_plain(uint32_t w, uint32_t &bad)
 {
-    const int cnt = n - first;
-    if (cnt <= 0) return;
-    const uint32_t keep = cnt >= 4 ? 0xffffffffu : ((1u << (8 * cnt)) - 1u);
     const uint32_t idx = (w >> 1) & 0x03030303u;
     const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, idx);      // 'A','C','T','G' by idx
-    bad |= (w ^ expect) & keep;
-    const uint32_t code = (idx ^ ((idx >> 1) & 0x01010101u)) & keep;          // A0 C1 G2 T3
-    const uint32_t code_byte = (code * 0x40100401u) >> 24;                    // first base in the top bits
-    codes |= (uint64_t)code_byte << (56 - 8 * (first >> 2));
+    bad |= w ^ expect;
+    const uint32_t code = idx ^ ((idx >> 1) & 0x01010101u);                   // A0 C1 G2 T3
+    return code * 0x40100401u;                                                // first base in the top bits of byte 3
+}
+// the top bytes of four such products as one word, the first on top
+__device__ __forceinline__ uint32_t top_bytes(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3)
+{
+    const uint32_t a = __builtin_amdgcn_perm(p0, p1, 0x07030000u);            // byte 3 of p0, byte 3 of p1, -, -
+    const uint32_t b = __builtin_amdgcn_perm(p2, p3, 0x00000703u);            // -, -, byte 3 of p2, byte 3 of p3
+    return __builtin_amdgcn_perm(a, b, 0x07060100u);
 }
 
+// (4.2 TB/s of the ~6.3 a copy reaches: two, or four, words per lane with their loads issued phase
+// by phase -- offsets, then bases -- ran in the same time, and so did this fast path with half the
+// instructions of the one before it: profiles/r04_ab_map.log)
 __global__ void __launch_bounds__(256)
 pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offsets,
                   int64_t n_reads, int words_per_read, int record_words, uint32_t *__restrict__ records)
 {
     const int64_t total = n_reads * (int64_t)words_per_read;
     const int64_t end_of_bases = offsets[n_reads];
+    const bool shifting = (words_per_read & (words_per_read - 1)) == 0;      // (4 words for reads of up to 128 bases)
+    const int shift = __builtin_ctz((unsigned)words_per_read);
     for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
-        // (32-bit division when the index fits: the 64-bit one is a long software routine)
-        const int64_t r = total <= 0xffffffffLL ? (int64_t)((uint32_t)g / (uint32_t)words_per_read)
-                                                : g / words_per_read;
+        // (a shift, or a 32-bit division when the index fits: the 64-bit one is a long software routine)
+        const int64_t r = shifting ? g >> shift
+                                   : total <= 0xffffffffLL ? (int64_t)((uint32_t)g / (uint32_t)words_per_read)
+                                                           : g / words_per_read;
         const int w = (int)(g - r * words_per_read);
         const int64_t begin = offsets[r];
         const int len = (int)(offsets[r + 1] - begin);
@@ -96,14 +108,14 @@ pack_reads_kernel(const uint8_t *__restrict__ bases, const int64_t *__restrict__
                 const Bytes16 lo = *reinterpret_cast<const Bytes16 *>(bases + at);
                 const Bytes16 hi = *reinterpret_cast<const Bytes16 *>(bases + at + 16);
                 uint32_t bad = 0;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) pack_dword_plain(lo.w[d], 4 * d, n, c, bad);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) pack_dword_plain(hi.w[d], 16 + 4 * d, n, c, bad);
+                const uint32_t first16 = top_bytes(pack_dword_plain(lo.w[0], bad), pack_dword_plain(lo.w[1], bad),
+                                                   pack_dword_plain(lo.w[2], bad), pack_dword_plain(lo.w[3], bad));
+                const uint32_t last16 = top_bytes(pack_dword_plain(hi.w[0], bad), pack_dword_plain(hi.w[1], bad),
+                                                  pack_dword_plain(hi.w[2], bad), pack_dword_plain(hi.w[3], bad));
                 if (bad == 0) {
                     m = n >= 32 ? 0xffffffffu : ~(0xffffffffu >> n);      // n upper-case ACGT bases
+                    c = (((uint64_t)first16 << 32) | last16) & (n >= 32 ? ~0ULL : ~(~0ULL >> (2 * n)));
                 } else {                                   // N, lower case, anything else: the full rule
-                    c = 0;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) pack_dword(lo.w[d], 4 * d, n, c, m);
 #pragma unroll
