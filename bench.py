@@ -377,6 +377,7 @@ def e2e_legs(args, hip, _native, index, device, bases, offsets, n_units, n_tx, p
                                                     'batches': fastq_pieces}
     finally:
         host.skm_fastq_cache_bytes(0)
+        host.skm_fastq_wait_unmapped()       # (the text's mappings go in the background: not under the next leg)
         shutil.rmtree(folder, ignore_errors=True)
     return out
 
@@ -509,6 +510,11 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
     for _ in range(warmup):
         step()
     state['boot_s'], state['boot_iters'] = 0.0, 0
+    # (handles of earlier legs that only the cycle collector can reach are destroyed NOW, not by a
+    # collection that happens to start inside the timed steps: their device memory goes back with
+    # synchronous hipFree calls -- seen once as 90 ms inside configs[3]'s EM phase)
+    import gc
+    gc.collect()
     t_before = result.timing()
     barrier()
     t0 = time.perf_counter()

@@ -406,6 +406,11 @@ int skm_fastq_cache_bytes(int64_t bytes);
  * n_threads helper threads -- for a run that knows its FASTQ files while it is still loading the index
  * (setting up the page tables of the text costs as much as parsing it).  A reader opened before
  * _finish finds the mappings in place; _finish stops the helpers and drops what nobody has open. */
+/* File mappings that no reader uses any more (beyond skm_fastq_cache_bytes) are unmapped by a
+ * background thread in small pieces.  _wait_unmapped returns once none of that is under way: for a
+ * caller about to time a phase that faults pages or allocates -- both wait for the process's
+ * memory-map lock, which the teardown takes over and over. */
+int skm_fastq_wait_unmapped(void);
 typedef struct skm_fastq_prefault skm_fastq_prefault;
 int skm_fastq_prefault_start(const char *const *paths, int n_paths, int n_threads, skm_fastq_prefault **out);
 int skm_fastq_prefault_finish(skm_fastq_prefault *handle);

@@ -146,6 +146,7 @@ HOST_SYMBOLS = {
     'skm_fastq_recycle': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'skm_fastq_close': (ctypes.c_int, [ctypes.c_void_p]),
     'skm_fastq_cache_bytes': (ctypes.c_int, [c_i64]),
+    'skm_fastq_wait_unmapped': (ctypes.c_int, []),
     'skm_fastq_packed_open': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, c_i64, ctypes.c_int, c_void_pp]),
     'skm_fastq_packed_open_ranges': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.c_int,

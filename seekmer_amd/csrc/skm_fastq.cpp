@@ -197,12 +197,27 @@ void collect_droppable(std::vector<std::pair<const char *, size_t>> &drop)
     }
 }
 
+std::atomic<int> g_unmapping{0};      // background teardowns under way (skm_fastq_wait_unmapped)
+
 void drop_in_background(std::vector<std::pair<const char *, size_t>> drop)
 {
-    if (!drop.empty())
-        std::thread([drop]() { for (auto &d : drop) unmap_in_pieces(d.first, d.second); }).detach();
+    if (drop.empty()) return;
+    g_unmapping.fetch_add(1);
+    std::thread([drop]() {
+        for (auto &d : drop) unmap_in_pieces(d.first, d.second);
+        g_unmapping.fetch_sub(1);
+    }).detach();
 }
 }  // namespace
+
+// Mappings that nobody uses any more are torn down by a background thread, a few MB at a time
+// (above).  Whoever is about to time something that faults pages or allocates (both queue behind
+// the teardown's hold on the process's memory-map lock) waits here first.
+extern "C" int skm_fastq_wait_unmapped(void)
+{
+    while (g_unmapping.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    return SKM_OK;
+}
 
 void set_map_keep_bytes(size_t bytes)
 {
