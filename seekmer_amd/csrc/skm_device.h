@@ -65,11 +65,12 @@ struct ContigEntry {                                             // _common.pxd:
 constexpr int CONTIG_INLINE_TARGETS = 9;
 constexpr int CONTIG_SHIFT = 7;
 constexpr uint32_t SUCC_ABSENT = 0, SUCC_AT_START = 1, SUCC_AT_END = 2, SUCC_LOOKUP = 3;
+constexpr uint32_t SUCC_WHOLE = 4;             // bit 2: the landing contig's list holds this contig's whole list
 constexpr int32_t OFFSET_AT_END = INT32_MAX;   // Coord.offset of a successor until its contig's length is known
 struct alignas(64) DevSide {
     int32_t offset, length;            // the contig in the pooled bases
     uint32_t count_edge;               // min(target_length, 0xffff) << 16 | the 8 bases at this end (first on top)
-    int32_t succ[4];                   // entry << 2 | SUCC_* of the four junction k-mers of this end
+    int32_t succ[4];                   // entry << 3 | SUCC_WHOLE | SUCC_* of the four junction k-mers of this end
     int32_t targets[CONTIG_INLINE_TARGETS];   // the slice; or [0] = its place in DevIndex::targets, [1] = its length
 };
 struct alignas(128) DevContig { DevSide side[2]; };      // [0] the contig's end, [1] its start
@@ -429,12 +430,14 @@ __device__ __forceinline__ SideVisit visit(const DevIndex &ix, Coord anchor, boo
     v.edge8 = count_edge & 0xffffu;
     return v;
 }
-__device__ __forceinline__ Coord junction_successor(const int32_t (&succ)[4], bool forward, uint32_t base, uint32_t &kind)
+__device__ __forceinline__ Coord junction_successor(const int32_t (&succ)[4], bool forward, uint32_t base, uint32_t &kind,
+                                                    bool &whole)
 {
     const uint32_t b = forward ? base : 3u - base;
     const int32_t word = b == 0 ? succ[0] : b == 1 ? succ[1] : b == 2 ? succ[2] : succ[3];
     kind = (uint32_t)word & 3u;
-    const int32_t entry = word >> 2;
+    whole = ((uint32_t)word & SUCC_WHOLE) != 0;
+    const int32_t entry = word >> 3;
     return Coord{forward ? entry : ~entry, kind == SUCC_AT_START ? 0 : OFFSET_AT_END};
 }
 

@@ -343,7 +343,38 @@ successor_build_kernel(DevIndex ix, DevContig *records, int64_t n_contigs, int f
             }
         }
         const bool placed = kind == SUCC_AT_START || kind == SUCC_AT_END;
-        records[c].side[side].succ[b] = (int32_t)((placed ? (uint32_t)pos.entry << 2 : 0u) | kind);
+        // SUCC_WHOLE: the landing contig's list holds every entry of this contig's (as multisets, in
+        // the orientation the hop arrives in).  A read's running list is a part of the list of the
+        // contig its anchor is on, so _filter_on_contig on the landing contig (_common.pyx:185-235)
+        // keeps all of it: the hop needs no merge.  Ascending slices only (two-pointer check).
+        bool whole = false;
+#ifndef SKM_NO_WHOLE
+        if (placed && ix.sorted_targets) {
+            const int64_t landing = pos.entry < 0 ? ~pos.entry : pos.entry;
+            const int32_t *all = reinterpret_cast<const int32_t *>(records);
+            auto slice = [&](int64_t contig, int32_t &start, int32_t &length) {
+                const DevSide &s0 = records[contig].side[0];
+                const int32_t count = (int32_t)(s0.count_edge >> 16);
+                if (count <= CONTIG_INLINE_TARGETS) { start = (int32_t)(contig * (2 * SIDE_WORDS) + SIDE_TARGETS_WORD); length = count; }
+                else { start = s0.targets[0]; length = s0.targets[1]; }
+            };
+            int32_t from, n_from, to, n_to;
+            slice(c, from, n_from);
+            slice(landing, to, n_to);
+            if (n_from <= n_to && n_to <= 4096) {
+                whole = true;
+                int32_t j = 0;
+                for (int32_t i = 0; i < n_from && whole; ++i) {
+                    const int32_t want = all[from + i];
+                    // the landing list in the arriving orientation, ascending
+                    auto at = [&](int32_t k) { return pos.entry >= 0 ? all[to + k] : ~all[to + n_to - 1 - k]; };
+                    while (j < n_to && at(j) < want) ++j;
+                    if (j < n_to && at(j) == want) ++j; else whole = false;
+                }
+            }
+        }
+#endif
+        records[c].side[side].succ[b] = (int32_t)((placed ? ((uint32_t)pos.entry << 3) | (whole ? SUCC_WHOLE : 0u) : 0u) | kind);
     }
 }
 
@@ -1134,8 +1165,12 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 // successors (a forward anchor's distance to the contig's left edge is its offset: whether
                 // this is a hop is known before the sector arrives, and a closing check asks for none) and,
                 // straight after a first hit, the contig's list (see first_hit).
-                const SideVisit at_side = visit<false>(ix, span.anchor, SUCCESSORS && (!forward || span.begin > span.anchor.offset),
+                // (an anchor that a merge-free hop has just put on its contig's last k-mer learns its offset here)
+                const bool at_end = span.anchor.offset == OFFSET_AT_END;
+                const SideVisit at_side = visit<false>(ix, span.anchor,
+                                                       SUCCESSORS && (at_end || !forward || span.begin > span.anchor.offset),
                                                        set.length < 0);
+                if (at_end) span.anchor.offset = at_side.length - K;
                 if (set.length < 0) map_contig<STATS>(ix, span.anchor, at_side, set, span, &ls);
                 if (span.n == 0) {                            // (a first hit without targets: as map_contig left it)
                     state = N_MATE_DONE;
@@ -1171,7 +1206,8 @@ map_units_kernel(DevIndex ix, MapBatch b)
                             // the junction lookup (:247-249), answered by the record of the contig the hop
                             // leaves: what A_LOOKUP does for Y_LJ, without the visit to the k-mer table
                             uint32_t kind;
-                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.begin), kind);
+                            bool whole;
+                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.begin), kind, whole);
                             if (kind == SUCC_LOOKUP) {            // (the k-mer words are needed: the first hit goes)
                                 kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)
                                        | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
@@ -1179,7 +1215,7 @@ map_units_kernel(DevIndex ix, MapBatch b)
                                 first_hit_kept = 0;
                             } else if (kind != SUCC_ABSENT) {
                                 span.anchor = landing;
-                                state = M_LJ;
+                                state = whole ? N_LEFT : M_LJ;        // (SUCC_WHOLE: the merge would keep everything)
                             } else {
                                 span.anchor = invalid_coord();
                                 if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }      // :250-259
@@ -1196,8 +1232,11 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 // -------------- _filter_targets_to_right: loop head + alignment step
                 const bool forward = span.anchor.entry >= 0;
                 const int rest = rv.len - span.end - K;
-                const SideVisit at_side = visit<true>(ix, span.anchor, SUCCESSORS && (forward || rest > span.anchor.offset),
+                const bool at_end = span.anchor.offset == OFFSET_AT_END;
+                const SideVisit at_side = visit<true>(ix, span.anchor,
+                                                      SUCCESSORS && (at_end || forward || rest > span.anchor.offset),
                                                       set.length < 0);
+                if (at_end) span.anchor.offset = at_side.length - K;
                 if (set.length < 0) map_contig<STATS>(ix, span.anchor, at_side, set, span, &ls);
                 if (span.n == 0) {                            // (a first hit without targets: as map_contig left it)
                     state = N_MATE_DONE;
@@ -1233,14 +1272,15 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         } else if (SUCCESSORS) {
                             // the junction lookup (:309-311) from the record: Y_RJ's part of A_LOOKUP
                             uint32_t kind;
-                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.end + K - 1), kind);
+                            bool whole;
+                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.end + K - 1), kind, whole);
                             if (kind == SUCC_LOOKUP) {
                                 kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)
                                         | read_code(rv, span.end + K - 1)) & KMER_MASK;
                                 state = Y_RJ;
                             } else if (kind != SUCC_ABSENT) {
                                 span.anchor = landing;
-                                state = M_RJ;
+                                state = whole ? N_RIGHT : M_RJ;
                             } else {                                                                  // :312-315
                                 span.anchor = invalid_coord();
                                 span.n = 0;
