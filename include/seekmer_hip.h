@@ -77,7 +77,7 @@ int skm_device_gather_ceiling(int device, int64_t table_bytes, int blocks, int p
  * handle owns device memory only.  Limits (SKM_ERR_ARG beyond them): n_slots a
  * power of two <= 2^31, n_contigs < 2^25, n_targets + 32 n_contigs < 2^30 (the
  * contig records -- two 64-byte sides, one per end of the contig -- carry the first
- * nine targets and the junction successors of that end: one int32 address space),
+ * eight targets and the junction successors of that end: one int32 address space),
  * n_bases < 2^31, at most 2^22 - 1 targets per contig.
  * skm_index_destroy gives up the caller's handle; the device copy is released once
  * every mapper created from it has been destroyed too (in either order). */

@@ -62,19 +62,22 @@ struct ContigEntry {                                             // _common.pxd:
 // successor sector (the first layout of round 4) cost two.  What only the fall-back paths need -- the
 // two edge k-mers themselves, for a hop that must look its junction k-mer up -- lives in an array of
 // its own (DevIndex::edge_kmers).
-constexpr int CONTIG_INLINE_TARGETS = 9;
+constexpr int CONTIG_INLINE_TARGETS = 8;
 constexpr int CONTIG_SHIFT = 7;
 constexpr uint32_t SUCC_ABSENT = 0, SUCC_AT_START = 1, SUCC_AT_END = 2, SUCC_LOOKUP = 3;
 constexpr uint32_t SUCC_WHOLE = 4;             // bit 2: the landing contig's list holds this contig's whole list
+constexpr uint32_t SUCC_MASKED = 8;            // bit 3: DevSide::kept says what the merge on the landing contig keeps
+constexpr int SUCC_ENTRY_SHIFT = 4;
 constexpr int32_t OFFSET_AT_END = INT32_MAX;   // Coord.offset of a successor until its contig's length is known
 struct alignas(64) DevSide {
     int32_t offset, length;            // the contig in the pooled bases
     uint32_t count_edge;               // min(target_length, 0xffff) << 16 | the 8 bases at this end (first on top)
-    int32_t succ[4];                   // entry << 3 | SUCC_WHOLE | SUCC_* of the four junction k-mers of this end
+    int32_t succ[4];                   // entry << 4 | SUCC_MASKED | SUCC_WHOLE | SUCC_* of the four junction k-mers of this end
+    uint8_t kept[4];                   // SUCC_MASKED: which entries of THIS contig's list (stored order) a hop's merge keeps
     int32_t targets[CONTIG_INLINE_TARGETS];   // the slice; or [0] = its place in DevIndex::targets, [1] = its length
 };
 struct alignas(128) DevContig { DevSide side[2]; };      // [0] the contig's end, [1] its start
-constexpr int SIDE_WORDS = 16, SIDE_TARGETS_WORD = 7;    // int32 words per side / offsetof(DevSide, targets) / 4
+constexpr int SIDE_WORDS = 16, SIDE_TARGETS_WORD = 8;    // int32 words per side / offsetof(DevSide, targets) / 4
 static_assert(sizeof(DevSide) == 64 && sizeof(DevContig) == (1u << CONTIG_SHIFT), "a side is one sector");
 static_assert(offsetof(DevSide, targets) == 4 * SIDE_TARGETS_WORD, "the inline targets close the sector");
 
@@ -402,6 +405,7 @@ struct SideVisit {
     int32_t offset, length;
     uint32_t edge8;
     int32_t succ[4];
+    uint32_t kept;                 // DevSide::kept, byte b for successor b
     Slice slice;
 };
 template <bool RIGHT>
@@ -416,8 +420,10 @@ __device__ __forceinline__ SideVisit visit(const DevIndex &ix, Coord anchor, boo
     v.length = record.length;
     const uint32_t count_edge = record.count_edge;
     v.succ[0] = v.succ[1] = v.succ[2] = v.succ[3] = 0;
+    v.kept = 0;
     if (successors) {
         v.succ[0] = record.succ[0]; v.succ[1] = record.succ[1]; v.succ[2] = record.succ[2]; v.succ[3] = record.succ[3];
+        v.kept = *reinterpret_cast<const uint32_t *>(record.kept);
     }
     v.slice = Slice{0, 0};
     if (list) {
@@ -430,15 +436,25 @@ __device__ __forceinline__ SideVisit visit(const DevIndex &ix, Coord anchor, boo
     v.edge8 = count_edge & 0xffffu;
     return v;
 }
-__device__ __forceinline__ Coord junction_successor(const int32_t (&succ)[4], bool forward, uint32_t base, uint32_t &kind,
-                                                    bool &whole)
+// what the record says about the hop that the read's next base selects
+struct Hop {
+    Coord landing;                 // map_kmer of the junction k-mer (offset 0 or OFFSET_AT_END), when kind is AT_START / AT_END
+    uint32_t kind;                 // SUCC_ABSENT / AT_START / AT_END / LOOKUP
+    bool whole, masked;            // SUCC_WHOLE / SUCC_MASKED
+    uint32_t kept;                 // SUCC_MASKED: the entries of the leaving contig's list (stored order) that the merge keeps
+};
+__device__ __forceinline__ Hop junction_successor(const SideVisit &at_side, bool forward, uint32_t base)
 {
     const uint32_t b = forward ? base : 3u - base;
-    const int32_t word = b == 0 ? succ[0] : b == 1 ? succ[1] : b == 2 ? succ[2] : succ[3];
-    kind = (uint32_t)word & 3u;
-    whole = ((uint32_t)word & SUCC_WHOLE) != 0;
-    const int32_t entry = word >> 3;
-    return Coord{forward ? entry : ~entry, kind == SUCC_AT_START ? 0 : OFFSET_AT_END};
+    const int32_t word = b == 0 ? at_side.succ[0] : b == 1 ? at_side.succ[1] : b == 2 ? at_side.succ[2] : at_side.succ[3];
+    Hop hop;
+    hop.kind = (uint32_t)word & 3u;
+    hop.whole = ((uint32_t)word & SUCC_WHOLE) != 0;
+    hop.masked = ((uint32_t)word & SUCC_MASKED) != 0;
+    hop.kept = (at_side.kept >> (8 * b)) & 0xffu;
+    const int32_t entry = word >> SUCC_ENTRY_SHIFT;
+    hop.landing = Coord{forward ? entry : ~entry, hop.kind == SUCC_AT_START ? 0 : OFFSET_AT_END};
+    return hop;
 }
 
 // 32 consecutive 2-bit codes starting at base `p` of a packed array (first

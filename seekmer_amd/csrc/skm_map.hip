@@ -347,7 +347,8 @@ successor_build_kernel(DevIndex ix, DevContig *records, int64_t n_contigs, int f
         // the orientation the hop arrives in).  A read's running list is a part of the list of the
         // contig its anchor is on, so _filter_on_contig on the landing contig (_common.pyx:185-235)
         // keeps all of it: the hop needs no merge.  Ascending slices only (two-pointer check).
-        bool whole = false;
+        bool whole = false, masked = false;
+        uint32_t kept = 0;
 #ifndef SKM_NO_WHOLE
         if (placed && ix.sorted_targets) {
             const int64_t landing = pos.entry < 0 ? ~pos.entry : pos.entry;
@@ -361,20 +362,37 @@ successor_build_kernel(DevIndex ix, DevContig *records, int64_t n_contigs, int f
             int32_t from, n_from, to, n_to;
             slice(c, from, n_from);
             slice(landing, to, n_to);
+            // the landing list in the arriving orientation, ascending
+            auto at = [&](int32_t k) { return pos.entry >= 0 ? all[to + k] : ~all[to + n_to - 1 - k]; };
             if (n_from <= n_to && n_to <= 4096) {
                 whole = true;
                 int32_t j = 0;
                 for (int32_t i = 0; i < n_from && whole; ++i) {
                     const int32_t want = all[from + i];
-                    // the landing list in the arriving orientation, ascending
-                    auto at = [&](int32_t k) { return pos.entry >= 0 ? all[to + k] : ~all[to + n_to - 1 - k]; };
                     while (j < n_to && at(j) < want) ++j;
                     if (j < n_to && at(j) == want) ++j; else whole = false;
                 }
             }
+            // SUCC_MASKED: otherwise, for a short list without a transcript listed twice (which copies
+            // of one the walk keeps depends on the direction it is read in), the entries it keeps --
+            // all a read needs whose running list is still a part of THIS contig's list
+#ifndef SKM_NO_MASKED
+            if (!whole && n_from <= CONTIG_INLINE_TARGETS && n_to <= 4096) {
+                masked = true;
+                for (int32_t i = 1; i < n_from; ++i) masked = masked && all[from + i] != all[from + i - 1];
+                int32_t j = 0;
+                for (int32_t i = 0; i < n_from && masked; ++i) {
+                    const int32_t want = all[from + i];
+                    while (j < n_to && at(j) < want) ++j;
+                    if (j < n_to && at(j) == want) { kept |= 1u << i; ++j; }
+                }
+            }
+#endif
         }
 #endif
-        records[c].side[side].succ[b] = (int32_t)((placed ? ((uint32_t)pos.entry << 3) | (whole ? SUCC_WHOLE : 0u) : 0u) | kind);
+        records[c].side[side].kept[b] = (uint8_t)(masked ? kept : 0u);
+        records[c].side[side].succ[b] = (int32_t)((placed ? ((uint32_t)pos.entry << SUCC_ENTRY_SHIFT) | (whole ? SUCC_WHOLE : 0u)
+                                                            | (masked ? SUCC_MASKED : 0u) : 0u) | kind);
     }
 }
 
@@ -1017,6 +1035,26 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 }
             };
 
+            // The merge of a hop (_filter_on_contig on the landing contig, _common.pyx:185-235) settled by
+            // the record of the contig the hop LEAVES (span.anchor is still on it): nothing to do when
+            // the landing list holds this contig's whole list (SUCC_WHOLE: the running list is a part
+            // of it); a stored mask when the running list is still made of positions of THIS contig's
+            // list (SUCC_MASKED: no hop since the first hit in this direction).  false: the merge
+            // action does it -- also when the mask leaves nothing, so that the failing merge ends
+            // with the anchor the reference ends with.
+            auto merge_by_record = [&](const Hop &hop, bool forward) -> bool {
+                if (hop.whole) return true;
+                const int32_t contig = forward ? span.anchor.entry : ~span.anchor.entry;
+                if (!hop.masked || (set.start >> 5) != contig || set.forward != forward || set.length > CONTIG_INLINE_TARGETS)
+                    return false;
+                const uint32_t in_read_order = set.forward ? hop.kept : __brev(hop.kept) >> (32 - set.length);
+                const uint32_t keep = (uint32_t)set.word0 & in_read_order;
+                if (keep == 0) return false;
+                set.word0 = keep;
+                span.n = __builtin_popcount(keep);
+                return true;
+            };
+
             if (valid && action == A_START) {
                 rv = read_view(block_records, b.record_words, b.words_per_read, first_read + (uint32_t)mate);
                 attempt = 0;
@@ -1205,17 +1243,16 @@ map_units_kernel(DevIndex ix, MapBatch b)
                         } else if (SUCCESSORS) {
                             // the junction lookup (:247-249), answered by the record of the contig the hop
                             // leaves: what A_LOOKUP does for Y_LJ, without the visit to the k-mer table
-                            uint32_t kind;
-                            bool whole;
-                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.begin), kind, whole);
+                            const Hop hop = junction_successor(at_side, forward, read_code(rv, span.begin));
+                            const uint32_t kind = hop.kind;
                             if (kind == SUCC_LOOKUP) {            // (the k-mer words are needed: the first hit goes)
                                 kmer = (tail_kmer<STATS>(ix, span.anchor, &ls) >> 2)
                                        | ((uint64_t)read_code(rv, span.begin) << (2 * K - 2));
                                 state = Y_LJ;
                                 first_hit_kept = 0;
                             } else if (kind != SUCC_ABSENT) {
-                                span.anchor = landing;
-                                state = whole ? N_LEFT : M_LJ;        // (SUCC_WHOLE: the merge would keep everything)
+                                state = merge_by_record(hop, forward) ? N_LEFT : M_LJ;
+                                span.anchor = hop.landing;
                             } else {
                                 span.anchor = invalid_coord();
                                 if (span.begin < K) { span.begin = 0; state = N_RIGHT_ENTER; }      // :250-259
@@ -1271,16 +1308,15 @@ map_units_kernel(DevIndex ix, MapBatch b)
                             state = N_AFTER;
                         } else if (SUCCESSORS) {
                             // the junction lookup (:309-311) from the record: Y_RJ's part of A_LOOKUP
-                            uint32_t kind;
-                            bool whole;
-                            const Coord landing = junction_successor(at_side.succ, forward, read_code(rv, span.end + K - 1), kind, whole);
+                            const Hop hop = junction_successor(at_side, forward, read_code(rv, span.end + K - 1));
+                            const uint32_t kind = hop.kind;
                             if (kind == SUCC_LOOKUP) {
                                 kmer = ((tail_kmer<STATS>(ix, span.anchor, &ls) << 2)
                                         | read_code(rv, span.end + K - 1)) & KMER_MASK;
                                 state = Y_RJ;
                             } else if (kind != SUCC_ABSENT) {
-                                span.anchor = landing;
-                                state = whole ? N_RIGHT : M_RJ;
+                                state = merge_by_record(hop, forward) ? N_RIGHT : M_RJ;
+                                span.anchor = hop.landing;
                             } else {                                                                  // :312-315
                                 span.anchor = invalid_coord();
                                 span.n = 0;
