@@ -49,7 +49,14 @@ struct ContigEntry {                                             // _common.pxd:
 //     two low bits, SUCC_ABSENT (not in the table: a miss, _mapper.pyx:250, :312), SUCC_AT_START
 //     (offset 0), SUCC_AT_END (offset = that contig's length - k, filled in when the hop lands
 //     there and its record has arrived) or SUCC_LOOKUP (any other offset, or a k-mer stored without
-//     a position: the hop does the table lookup itself, as every hop did before);
+//     a position: the hop does the table lookup itself, as every hop did before).  Two more bits
+//     say what the list merge on the landing contig will do (KMerIndex._filter_on_contig,
+//     _common.pyx:185-235), where that is a function of the junction alone: SUCC_WHOLE -- it keeps the
+//     read's whole running list, because the landing list holds every entry of this contig's list,
+//     of which the running list is a part; SUCC_MASKED -- of THIS contig's list it keeps the entries
+//     whose bit is set in `kept` (short lists without a transcript listed twice), which settles the
+//     merge as long as the running list is made of positions of this contig's list.  Such a hop
+//     goes on to the next alignment step without a merge round;
 //   * the contig's first CONTIG_INLINE_TARGETS signed target entries (nine slices in ten have no
 //     more): the list arrives with the sector, and a merge (KMerIndex.map_contig /
 //     _filter_on_contig, _common.pyx:143-235) is one round trip.  Longer slices live behind the
