@@ -135,6 +135,74 @@ def test_hops_that_must_look_their_junction_up(oracle, native_libs, chr21, chr21
     _compare_tables(oracle, expected, fld, result)
 
 
+@pytest.mark.parametrize('paired', [True, False])
+def test_repeats_inside_transcripts_and_segments_shared_in_both_orientations(oracle, native_libs, paired):
+    """The junction flags of the contig records (skm_device.h: SUCC_WHOLE, SUCC_MASKED, DevSide::kept)
+    are worked out at upload from pairs of target lists; this transcriptome is made to stress them:
+    transcripts are chains of segments drawn from a small pool, any segment forwards or reverse
+    complemented and possibly several times in one transcript -- contigs that list a transcript
+    twice (no mask then: which copy a merge keeps depends on the direction), hops that land on
+    contigs in the other orientation, lists that are supersets and lists that are not at nearly
+    every junction, lists longer than the eight inline targets.  Per unit and per table against the
+    oracle (KMerIndex._filter_on_contig, seekmer/_common.pyx:185-235; _mapper.pyx:229-343)."""
+    from seekmer_amd import index_builder
+    rng = np.random.default_rng(2024)
+    comp = bytes.maketrans(b'ACGT', b'TGCA')
+    letters = np.frombuffer(b'ACGT', dtype=np.uint8)
+    segments = [bytes(rng.choice(letters, int(rng.integers(26, 140)))) for _ in range(40)]
+    transcripts = []
+    for _ in range(90):
+        parts = []
+        for _ in range(int(rng.integers(3, 10))):
+            seg = segments[int(rng.integers(len(segments)))]
+            parts.append(seg.translate(comp)[::-1] if rng.random() < 0.35 else seg)
+        if rng.random() < 0.5:                      # a segment twice in the same transcript, some way apart
+            parts.insert(int(rng.integers(len(parts) + 1)), parts[0])
+        transcripts.append(b''.join(parts))
+    ids = [b'R%04d' % i for i in range(len(transcripts))]
+    tx_offsets = np.concatenate([[0], np.cumsum([len(t) for t in transcripts])]).astype(np.int64)
+    pool = np.frombuffer(b''.join(transcripts) + b'\0', dtype=np.uint8).copy()
+    index = index_builder.build_pooled(ids, pool, tx_offsets)
+    counts = index.contigs['target_count']
+    assert counts.max() > 8 and index.device_info()['successors'] == 1
+    oindex = oracle.OracleIndex(index.kmers, index.contigs, index.sequences, index.targets,
+                                lengths=np.diff(tx_offsets))
+    # (a transcript listed twice by one contig: the case the masks must leave alone)
+    entries = index.targets[index.targets.dtype.names[0]]
+    starts = index.contigs['target_offset']
+    assert any(len(set(entries[a:a + n].tolist())) < n for a, n in zip(starts.tolist(), counts.tolist()))
+    if paired:                  # mates of one fragment (the adversarial reads are unrelated to one another)
+        reads = []
+        usable = [t for t in transcripts if len(t) > 320]
+        for u in range(6000):
+            t = usable[int(rng.integers(len(usable)))]
+            size = int(rng.integers(150, 320))
+            at = int(rng.integers(0, len(t) - size))
+            fragment = t[at:at + size]
+            mates = [bytearray(fragment[:100]), bytearray(fragment[-100:].translate(comp)[::-1])]
+            if u % 7 == 3:
+                mates.reverse()                                   # the fragment from the other strand
+            for m in mates:
+                roll = rng.random()
+                if roll < 0.25:
+                    m[int(rng.integers(len(m)))] = b'ACGT'[int(rng.integers(4))]
+                elif roll < 0.32:
+                    del m[int(rng.integers(5, len(m) - 5))]
+                elif roll < 0.39:
+                    m.insert(int(rng.integers(5, len(m) - 5)), b'ACGT'[int(rng.integers(4))])
+            reads += [bytes(m) for m in mates]
+    else:
+        reads = _adversarial_reads(transcripts, rng, 12000, 100)
+    bases, offsets = oracle.pack_reads(reads)
+    n_units = len(reads) // 2 if paired else len(reads)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(oindex, bases, offsets, n_units, paired, fld)
+    assert (expected.count > 0).mean() > 0.4
+    result, units = _run_gpu(index, bases, offsets, n_units, paired)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_edge_windows_and_pool_fallback(oracle, native_libs, chr21, chr21_oracle_index):
     """A built index takes the 8-base windows at contig ends from first_kmer/last_kmer
     (skm_index_info[6] == 1); an index whose edge k-mers do not spell the pooled bases
