@@ -44,7 +44,10 @@ struct MapBatch {
 #endif
 constexpr int MAP_THREADS = SKM_MAP_THREADS;
 constexpr int MAP_BLOCKS_PER_CU = 4;
-constexpr int MAP_CONTEXTS = 480;     // unit contexts per block: 16 words + 7 ring entries each, 4 blocks in 160 KB of LDS
+#ifndef SKM_MAP_CONTEXTS
+#define SKM_MAP_CONTEXTS 480
+#endif
+constexpr int MAP_CONTEXTS = SKM_MAP_CONTEXTS;   // unit contexts per block: 16 words + 7 ring entries each, 4 blocks in 160 KB of LDS
 
 void launch_pack_reads(const uint8_t *bases, const int64_t *offsets, int64_t n_reads,
                        int words_per_read, int record_words, uint32_t *records, hipStream_t stream);
