@@ -107,7 +107,12 @@ int skm_index_info(const skm_index *index, int64_t info[8]);
  * ask for when it leaves the contig, computed once at upload, so that a hop reads its answer
  * from the record instead of visiting the k-mer table (results identical by construction;
  * off for a table probed in the reference's layout).  A junction k-mer that is neither the
- * first nor the last k-mer of its contig -- none in a built index -- is marked "look it up". */
+ * first nor the last k-mer of its contig -- none in a built index -- is marked "look it up".
+ * [7]=slots of the signature table (0: none): per minimizer of the table's k-mers a 64-bit word
+ * that says which k-mers it has; the roll past a sequencing error (_find_first_kmer,
+ * seekmer/_mapper.pyx:207-216) asks it before the table -- a k-mer whose bit is clear is not in
+ * the table, and a run of the read's k-mers shares a minimizer.  Results identical by
+ * construction (no false negatives); SKM_NO_SIGNATURES=1 leaves it out. */
 int skm_index_layout(const skm_index *index, int64_t layout[8]);
 
 /* ------------------------------------------------------------------ mapper

@@ -81,7 +81,7 @@ class KMerIndex:
         layout = (ctypes.c_int64 * 8)()
         _native.check(_native.hip().skm_index_layout(self.device_handle(device), layout))
         out.update(zip(('bucketed', 'buckets', 'bucket_kmers', 'bucket_overflowed', 'kmers_twice',
-                        'slots_unreached', 'successors'), layout))
+                        'slots_unreached', 'successors', 'signature_slots'), layout))
         return out
 
     def release(self):

@@ -147,6 +147,8 @@ struct DevIndex {
     int32_t sorted_targets;    // every contig's target slice ascends by signed entry (built indices do)
     int32_t successors;        // every record carries its junction successors (see DevContig)
     const uint64_t *edge_kmers; // [2 * n_contigs]: first_kmer, last_kmer of every contig (fall-back paths)
+    const uint64_t *signatures; // [2 << (32 - signature_shift)] or nullptr: which k-mers a minimizer has (see kmer_min_hash)
+    uint32_t signature_shift;
     const DevBucket *buckets;  // the same set of k-mers by bucket, or nullptr (see DevBucket)
     uint32_t bucket_mask;      // number of buckets - 1 (a power of two)
     uint32_t bucket_shift;     // bucket = bucket_hash(canonical k-mer) >> bucket_shift
@@ -238,6 +240,7 @@ struct LaneStats {
 // sector costs one sector visit, and a longer one costs ceil() memory
 // latencies instead of one per slot.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 constexpr int PROBE = 4;
 template <bool STATS>
 __device__ __forceinline__ Coord map_kmer(const DevIndex &ix, uint64_t kmer, LaneStats *st)
@@ -466,6 +469,61 @@ __device__ __forceinline__ Hop junction_successor(const SideVisit &at_side, bool
     const int32_t entry = word >> SUCC_ENTRY_SHIFT;
     hop.landing = Coord{forward ? entry : ~entry, hop.kind == SUCC_AT_START ? 0 : OFFSET_AT_END};
     return hop;
+}
+
+// ---- signatures: what the first-hit roll asks before it asks the table --------------------------
+// A read with a sequencing error in its first k bases is rolled through up to k k-mers that are not
+// in the table, and every one of them costs a sector of a bucket that has nothing to do with the
+// one before: the roll is the largest single item of the mapper's sector budget.  Consecutive k-mers
+// share their MINIMIZER -- here: the smallest hash among the 13-mers of the k-mer and of its reverse
+// complement, 26 values of which a k-mer and its successor share 24 -- for six steps on average,
+// so a small table indexed by that hash is read once for a run of k-mers.  (13 bases: with 11 there
+// are 4 M possible minimizers of which a random order favours ~300 k, and 65 M k-mers saturate their
+// signatures.)  It holds, per slot, a 128-bit signature: two bits of it (signature_bits, from
+// bucket_hash(canonical k-mer)) are set for every k-mer of the table whose minimizer hashes there.
+// A k-mer with one of its bits clear is not in the table -- no false negatives: slots that collide
+// only add bits --; one with both set is looked up as before.
+constexpr int MINIMIZER_BASES = 13;
+constexpr int MINIMIZERS_PER_KMER = K - MINIMIZER_BASES + 1;      // 15 per strand
+__device__ __forceinline__ uint32_t mmer_hash(uint32_t mmer)
+{
+    uint32_t h = mmer * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    return h ^ (h >> 13);
+}
+__device__ __forceinline__ uint32_t kmer_min_hash(uint64_t kmer)
+{
+    const uint64_t rc = kmer_revcomp(kmer);
+    uint32_t least = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < MINIMIZERS_PER_KMER; ++i) {
+        least = min(least, mmer_hash((uint32_t)(kmer >> (2 * i)) & ((1u << (2 * MINIMIZER_BASES)) - 1u)));
+        least = min(least, mmer_hash((uint32_t)(rc >> (2 * i)) & ((1u << (2 * MINIMIZER_BASES)) - 1u)));
+    }
+    return least;
+}
+struct Signature { uint64_t lo, hi; };           // 128 bits per slot
+__device__ __forceinline__ Signature signature_bits(uint32_t bucket_hash_of_kmer)
+{
+    const uint32_t a = bucket_hash_of_kmer & 127u, b = (bucket_hash_of_kmer >> 7) & 127u;
+    Signature s{0, 0};
+    if (a < 64) s.lo |= 1ULL << a; else s.hi |= 1ULL << (a - 64);
+    if (b < 64) s.lo |= 1ULL << b; else s.hi |= 1ULL << (b - 64);
+    return s;
+}
+// the slot of a minimizer hash: the smallest of 30 hashes is a small number -- mixed again (a
+// bijection) before its top bits pick the slot
+__device__ __forceinline__ uint32_t signature_slot(uint32_t least, uint32_t shift)
+{
+    return mmer_hash(least ^ 0x5bd1e995u) >> shift;
+}
+// reverse complement of 32 bases in a word (first base in the top bits)
+__device__ __forceinline__ uint64_t revcomp32(uint64_t k)
+{
+    k = ((k >> 2) & 0x3333333333333333ULL) | ((k & 0x3333333333333333ULL) << 2);
+    k = ((k >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((k & 0x0f0f0f0f0f0f0f0fULL) << 4);
+    return ~__builtin_bswap64(k);
 }
 
 // 32 consecutive 2-bit codes starting at base `p` of a packed array (first

@@ -71,6 +71,8 @@ void launch_offsets_uniform(int64_t *offsets, int64_t n_reads, int64_t read_len,
 void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *buckets, uint32_t bucket_mask,
                          uint32_t bucket_shift, unsigned long long *report, hipStream_t stream);
 // DevContig::succ of every record, by lookups over ix's bucket table (skm_index_create, once)
+void launch_signature_build(const DevBucket *buckets, uint64_t n_buckets, uint64_t *signatures, uint32_t shift,
+                            hipStream_t stream);
 void launch_successor_build(const DevIndex &ix, DevContig *records, int64_t n_contigs, int force_lookup,
                             hipStream_t stream);
 // stats: 0 production, 1 counting build, 2 census build (skm_map.hip)

@@ -293,6 +293,23 @@ bucket_pack_kernel(DevBucketBuild *buckets, uint64_t n_buckets)
     }
 }
 
+// The signatures of the k-mers in the packed buckets (skm_device.h: kmer_min_hash): a lane per entry.
+__global__ void __launch_bounds__(256)
+signature_build_kernel(const DevBucket *buckets, uint64_t n_buckets, unsigned long long *signatures, uint32_t shift)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_buckets * 4;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const DevBucket &bucket = buckets[i >> 2];
+        const uint32_t low = bucket.low[i & 3];
+        if (low == BUCKET_FREE) continue;
+        const uint64_t canonical = ((uint64_t)(bucket.high[i & 3] & BUCKET_HIGH_MASK) << 31) | low;
+        const Signature bits = signature_bits(bucket_hash(canonical));
+        unsigned long long *slot = signatures + 2 * (size_t)signature_slot(kmer_min_hash(canonical), shift);
+        if (bits.lo) atomicOr(slot, bits.lo);
+        if (bits.hi) atomicOr(slot + 1, bits.hi);
+    }
+}
+
 // The bucket table answers "is this k-mer in the set, and with which position"; the
 // reference's probe (_common.pyx:75-97) answers the same question exactly when it finds every
 // stored k-mer in the slot that stores it.  report[3] counts the slots where it does not
@@ -816,6 +833,7 @@ enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_
 #define SKM_SCAN_ROUNDS 5
 #endif
 constexpr int SCAN_ROUNDS = SKM_SCAN_ROUNDS;    // k-mers one round of the first-hit roll looks up together
+constexpr int SIGNED_CANDIDATES = 7;            // ... with the signatures in front: a window of k + 6 bases of the read
 
 
 constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
@@ -1097,6 +1115,86 @@ map_units_kernel(DevIndex ix, MapBatch b)
                 } else {                                      // Y_LS :260-263, Y_RJ :312-315
                     span.n = 0;
                     state = N_AFTER;
+                }
+            } else if (valid && action == A_SCAN && BUCKETS && ix.signatures != nullptr) {
+                // ------------- _find_first_kmer's roll, :207-216, with the signatures in front of the bucket
+                // table (skm_device.h: kmer_min_hash): up to SIGNED_CANDIDATES k-mers of the read -- the one
+                // at hand and those its next bases make, a window of 32 bases -- ask the signature of their
+                // minimizer (a run of k-mers shares it: one or two sectors for the lot) whether they can be
+                // in the table at all; the few that can ask for the `low` words of their buckets together,
+                // and the judging goes in read order as in the plain roll below: the first hit is the one
+                // the reference's one-by-one roll stops at.
+                constexpr int N = SIGNED_CANDIDATES;
+                uint32_t more = 0;
+                int m = 1;
+#pragma unroll
+                for (int j = 1; j < N; ++j) {
+                    const int at = scan_i + j - 1;                 // the base that makes candidate j
+                    const bool ok = m == j && at < rv.len && (at >> 4) == (scan_i >> 4);
+                    more = (more << 2) | (ok ? (look >> (30 - 2 * (at & 15))) & 3u : 0u);
+                    m += ok ? 1 : 0;
+                }
+                const uint64_t window = (kmer << (2 * (N - 1))) | more;   // candidate j = bases j .. j + k - 1 of it
+                const uint64_t mirror = revcomp32(window) >> (2 * (32 - (K + N - 1)));   // its reverse complement = bases N-1-j .. of this
+                uint32_t forward[K - MINIMIZER_BASES + N], backward[K - MINIMIZER_BASES + N];
+#pragma unroll
+                for (int s = 0; s < K - MINIMIZER_BASES + N; ++s) {
+                    forward[s] = mmer_hash((uint32_t)(window >> (2 * (K - MINIMIZER_BASES + N - 1 - s))) & ((1u << (2 * MINIMIZER_BASES)) - 1u));
+                    backward[s] = mmer_hash((uint32_t)(mirror >> (2 * (K - MINIMIZER_BASES + N - 1 - s))) & ((1u << (2 * MINIMIZER_BASES)) - 1u));
+                }
+                // (a run of candidates shares its minimizer: the signature is asked for once per run)
+                u64x2 signature[N];
+                uint32_t slot = 0xffffffffu;
+                u64x2 word{0, 0};
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    uint32_t least = 0xffffffffu;
+#pragma unroll
+                    for (int i = 0; i < MINIMIZERS_PER_KMER; ++i)
+                        least = min(least, min(forward[j + i], backward[N - 1 - j + i]));
+                    const uint32_t mine = signature_slot(least, ix.signature_shift);
+                    if (j < m && mine != slot) {
+                        slot = mine;
+                        word = *reinterpret_cast<const u64x2 *>(ix.signatures + 2 * (size_t)slot);
+                    }
+                    signature[j] = word;
+                }
+                uint32_t possible = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const uint64_t candidate = (window >> (2 * (N - 1 - j))) & KMER_MASK;
+                    const uint64_t rc = (mirror >> (2 * j)) & KMER_MASK;
+                    const Signature wanted = signature_bits(bucket_hash(candidate < rc ? candidate : rc));
+                    if (j < m && (signature[j].x & wanted.lo) == wanted.lo && (signature[j].y & wanted.hi) == wanted.hi)
+                        possible |= 1u << j;
+                }
+                if (STATS) { ls.lookups += (uint32_t)m; ls.slots += (uint32_t)__builtin_popcount(possible); }   // (census: asked / passed)
+                // In read order, the candidates that can be in the table are looked up one after the other:
+                // the first of them is nearly always the hit the roll is after (the k-mers before it hold
+                // the sequencing error and were turned away by their signatures), and the k-mers behind a
+                // hit are in the table too -- asking for their buckets up front fetched three sectors per
+                // round for nothing.  A candidate that was turned away is a miss (invalid_coord, as
+                // map_kmer returns it); span.anchor is the result of the LAST k-mer the roll looked at.
+                int last = m - 1;
+                Coord pos = invalid_coord();
+                for (uint32_t todo = possible; todo != 0; todo &= todo - 1) {
+                    const int j = __builtin_ctz(todo);
+                    const Coord got = map_kmer_buckets_whole(ix, (window >> (2 * (N - 1 - j))) & KMER_MASK);
+                    if (got.offset >= 0) { pos = got; last = j; break; }
+                    if (j == m - 1) pos = got;         // (stored without a position, offset < 0: a miss that leaves its trace)
+                }
+                kmer = (window >> (2 * (N - 1 - last))) & KMER_MASK;      // the k-mer of candidate `last`
+                scan_i += last;
+                span.anchor = pos;
+                if (pos.offset >= 0) {
+                    first_hit(pos);
+                } else if (scan_i < rv.len) {
+                    if ((scan_i >> 4) != ((scan_i - last) >> 4)) look = read_half(rv, scan_i >> 4);
+                    kmer = ((kmer << 2) | ((look >> (30 - 2 * (scan_i & 15))) & 3u)) & KMER_MASK;
+                    ++scan_i;
+                    if ((scan_i & 15) == 0 && scan_i < rv.len) look = read_half(rv, scan_i >> 4);
+                } else {
+                    state = N_MATE_DONE;
                 }
             } else if (valid && action == A_SCAN && BUCKETS) {
                 // ------------- _find_first_kmer's roll, :207-216, over the bucket table: the next
@@ -1615,6 +1713,13 @@ void launch_bucket_build(const DevIndex &ix, uint64_t n_slots, DevBucket *bucket
                        bucket_mask, bucket_shift, report);
     hipLaunchKernelGGL(bucket_pack_kernel, dim3(4096), dim3(256), 0, stream, filling, (uint64_t)bucket_mask + 1);
     hipLaunchKernelGGL(probe_check_kernel, dim3(4096), dim3(256), 0, stream, ix, n_slots, report);
+}
+
+void launch_signature_build(const DevBucket *buckets, uint64_t n_buckets, uint64_t *signatures, uint32_t shift,
+                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(signature_build_kernel, dim3(4096), dim3(256), 0, stream, buckets, n_buckets,
+                       reinterpret_cast<unsigned long long *>(signatures), shift);
 }
 
 void launch_successor_build(const DevIndex &ix, DevContig *records, int64_t n_contigs, int force_lookup,
