@@ -375,22 +375,30 @@ __device__ __forceinline__ Coord map_kmer_buckets(const DevIndex &ix, uint64_t k
 // The same with the home bucket's four positions asked for together with its keys (the whole
 // sector in one go): the position of the entry that matches is then a register select and not a
 // second, dependent access -- for the lookups that expect a hit.
-__device__ __forceinline__ Coord map_kmer_buckets_whole(const DevIndex &ix, uint64_t kmer)
+struct BucketLoads { BucketKeys keys; u32x4 p01, p23; };       // (asked for; nothing waits for them yet)
+__device__ __forceinline__ BucketLoads bucket_loads(const DevIndex &ix, uint64_t kmer)
 {
     const uint64_t rc = kmer_revcomp(kmer);
     const uint32_t b = bucket_hash(kmer < rc ? kmer : rc) >> ix.bucket_shift;
-    const BucketKeys keys = bucket_keys(ix, b);
     const u32x4 *p = reinterpret_cast<const u32x4 *>(bucket_at(ix, b)->pos);
-    const u32x4 p01 = bucket_load(p), p23 = bucket_load(p + 1);
+    return BucketLoads{bucket_keys(ix, b), bucket_load(p), bucket_load(p + 1)};
+}
+__device__ __forceinline__ Coord map_kmer_in(const DevIndex &ix, const BucketLoads &bucket, uint64_t kmer)
+{
+    const uint64_t rc = kmer_revcomp(kmer);
     bool flip = false;
-    const int j = bucket_find(keys, kmer, rc, flip);
+    const int j = bucket_find(bucket.keys, kmer, rc, flip);
     if (j >= 0) {
-        const uint32_t entry = j == 0 ? p01.x : j == 1 ? p01.z : j == 2 ? p23.x : p23.z;
-        const uint32_t offset = j == 0 ? p01.y : j == 1 ? p01.w : j == 2 ? p23.y : p23.w;
+        const uint32_t entry = j == 0 ? bucket.p01.x : j == 1 ? bucket.p01.z : j == 2 ? bucket.p23.x : bucket.p23.z;
+        const uint32_t offset = j == 0 ? bucket.p01.y : j == 1 ? bucket.p01.w : j == 2 ? bucket.p23.y : bucket.p23.w;
         return Coord{(int32_t)(flip ? ~entry : entry), (int32_t)offset};
     }
     if (j == -1) return invalid_coord();
     return map_kmer_buckets(ix, kmer);              // a full bucket: the chain from the start
+}
+__device__ __forceinline__ Coord map_kmer_buckets_whole(const DevIndex &ix, uint64_t kmer)
+{
+    return map_kmer_in(ix, bucket_loads(ix, kmer), kmer);
 }
 
 // The k-mer whose map_kmer result side `side`, successor `b` of a record holds (see DevContig): the

@@ -203,6 +203,55 @@ def test_repeats_inside_transcripts_and_segments_shared_in_both_orientations(ora
     _compare_tables(oracle, expected, fld, result)
 
 
+@pytest.mark.parametrize('signatures', [True, False])
+def test_the_roll_with_and_without_signatures(oracle, native_libs, chr21, chr21_oracle_index, signatures, monkeypatch):
+    """_find_first_kmer's roll (seekmer/_mapper.pyx:207-216) asks a table of signatures by minimizer
+    before the k-mer table (skm_device.h: kmer_min_hash; skm_index_layout[7]); SKM_NO_SIGNATURES=1
+    leaves it out and the roll asks the buckets of five k-mers at a time.  Reads made for the roll:
+    substitutions in the first k bases (one, two, at either end of the first k-mer), the first 30 or
+    60 bases random, Ns in front, reads that map nowhere, reads just k + 1 long -- the first hit and
+    everything behind it as the oracle's."""
+    if not signatures:
+        monkeypatch.setenv('SKM_NO_SIGNATURES', '1')
+    rng = np.random.default_rng(19)
+    comp = bytes.maketrans(b'ACGT', b'TGCA')
+    long_tx = [s for s in chr21[1] if len(s) > 400]
+    reads = []
+    for i in range(8000):
+        t = long_tx[int(rng.integers(len(long_tx)))]
+        at = int(rng.integers(0, len(t) - 130))
+        r = bytearray(t[at:at + 100].upper())
+        kind = i % 10
+        if kind in (0, 1, 2):
+            for _ in range(1 + (kind == 2)):
+                q = int(rng.integers(0, 25 if kind else 3))
+                r[q] = b'ACGT'[(b'ACGT'.index(bytes([r[q]])) + 1 + int(rng.integers(3))) % 4] if bytes([r[q]]) in b'ACGT' else ord('A')
+        elif kind == 3:
+            r[24] = ord('N')
+        elif kind == 4:
+            r[:30] = bytes(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), 30))
+        elif kind == 5:
+            r[:60] = bytes(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), 60))
+        elif kind == 6:
+            r = bytearray(bytes(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), 100)))
+        elif kind == 7:
+            r = r[:26]
+            r[0] = ord('N')
+        elif kind == 8:
+            r[:3] = b'NNN'
+        if i % 3 == 0:
+            r = bytearray(bytes(r).translate(comp)[::-1])
+        reads.append(bytes(r))
+    index = make_product_index(chr21_oracle_index, chr21[0])
+    assert (index.device_info()['signature_slots'] > 0) == signatures
+    bases, offsets = oracle.pack_reads(reads)
+    fld = np.zeros(2000, dtype=np.int64)
+    expected = oracle.map_batch(chr21_oracle_index, bases, offsets, len(reads), False, fld)
+    result, units = _run_gpu(index, bases, offsets, len(reads), False)
+    _compare_units(expected, units)
+    _compare_tables(oracle, expected, fld, result)
+
+
 def test_edge_windows_and_pool_fallback(oracle, native_libs, chr21, chr21_oracle_index):
     """A built index takes the 8-base windows at contig ends from first_kmer/last_kmer
     (skm_index_info[6] == 1); an index whose edge k-mers do not spell the pooled bases
