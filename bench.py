@@ -584,7 +584,9 @@ def measure(args, ctx, config, steps, warmup, n_units=0, read_len=0, bootstraps=
         elif config == 1 and args.genes == 20000 and n_units == 10_000_000 and read_len == 100:
             traffic = pmc['derived']['hbm_traffic_bytes']
             traffic_source = 'quoted from %s (rocprofv3 --pmc passes of this build on this workload), ' \
-                             'not measured by this run' % PMC_SUMMARY
+                             'not measured by this run; below the algorithmic bytes where the product ' \
+                             'proves k-mers absent without the bucket reads the reference\'s probe makes ' \
+                             '(signatures by minimizer, DESIGN.md 4)' % PMC_SUMMARY
             miss_rate = pmc['per_launch']['TCC_MISS_sum'] / (map_ns * 1e-9)
     except (OSError, KeyError, ValueError):
         pass

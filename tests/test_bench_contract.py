@@ -46,7 +46,10 @@ def test_committed_bench_lines_follow_the_contract(name, config):
         roofline['algorithmic_bytes_per_launch'] / (roofline['launch_ms'] * 1e-3) / 1e9, rel=1e-6)
     assert 0 < roofline['frac'] < 1
     if roofline['traffic'] is not None:          # (quoted from the PMC passes of the same build)
-        assert roofline['traffic'] >= roofline['algorithmic_bytes_per_launch']
+        # (up to the middle of round 4 the counters showed MORE than the algorithmic bytes -- wasted
+        # re-reads; since the signatures of the first-hit roll they show less: the product proves most
+        # of the roll's k-mers absent without touching the buckets the reference's probe reads)
+        assert 0.5 * roofline['algorithmic_bytes_per_launch'] < roofline['traffic'] < 3 * roofline['algorithmic_bytes_per_launch']
         assert 'profiles/' in roofline['traffic_source']
     cpu = line['cpu_baseline']
     for field in ('value', 'unit', 'cores', 'kind', 'sample'):
