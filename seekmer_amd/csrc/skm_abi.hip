@@ -684,32 +684,35 @@ extern "C" int skm_index_create(const void *kmers, int64_t n_slots, const void *
                 ix->bytes += (int64_t)n_buckets * (int64_t)sizeof(DevBucket);
                 ix->layout[0] = 1;
                 const char *no_sig = getenv("SKM_NO_SIGNATURES");        // tuning aid: the roll asks the buckets straight away
-                if (!(no_sig && no_sig[0] == '1')) {
-                    // signatures of the k-mers by minimizer (skm_device.h: kmer_min_hash): a slot per four k-mers
-                    int sig_bits = 10;
-                    while (sig_bits < 30 && (4LL << sig_bits) < occupied) ++sig_bits;
-                    HIP_TRY(hipMalloc(&ix->signatures, 2 * sizeof(uint64_t) << sig_bits));
-                    HIP_TRY(hipMemset(ix->signatures, 0, 2 * sizeof(uint64_t) << sig_bits));
+                // signatures of the k-mers by minimizer (skm_device.h: kmer_min_hash): a slot per four k-mers
+                int sig_bits = 10;
+                while (sig_bits < 30 && (4LL << sig_bits) < occupied) ++sig_bits;
+                const size_t sig_bytes = 2 * sizeof(uint64_t) << sig_bits;
+                if (!(no_sig && no_sig[0] == '1') && hipMalloc(&ix->signatures, sig_bytes) != hipSuccess) {
+                    (void)hipGetLastError();                   // (no room: the roll asks the buckets, as without them)
+                    ix->signatures = nullptr;
+                }
+                if (ix->signatures) {
+                    HIP_TRY(hipMemset(ix->signatures, 0, sig_bytes));
                     launch_signature_build((const DevBucket *)ix->buckets, n_buckets, (uint64_t *)ix->signatures,
                                            (uint32_t)(32 - sig_bits), nullptr);
                     HIP_TRY(hipGetLastError());
                     HIP_TRY(hipDeviceSynchronize());
                     if (getenv("SKM_TRACE_SIGNATURES")) {       // tuning aid: how full the signatures are
-                        std::vector<uint64_t> head((size_t)1 << 20);
+                        std::vector<uint64_t> head(std::min<size_t>((size_t)1 << 20, sig_bytes / 8));
                         HIP_TRY(hipMemcpy(head.data(), ix->signatures, head.size() * 8, hipMemcpyDeviceToHost));
-                        int64_t bits = 0, used = 0, hist[66] = {0};
+                        int64_t bits = 0, used = 0, full = 0;
                         for (size_t k = 0; k + 1 < head.size(); k += 2) {
-                            const int c = (__builtin_popcountll(head[k]) + __builtin_popcountll(head[k + 1])) / 2;
-                            bits += 2 * c; used += 2 * (c != 0); hist[c]++;
+                            const int c = __builtin_popcountll(head[k]) + __builtin_popcountll(head[k + 1]);
+                            bits += c; used += c != 0; full += c == 128;
                         }
-                        fprintf(stderr, "[skm_index_create] signatures: %d slot bits, first 2^20 slots: %.2f bits per slot, %.1f %% used;",
-                                sig_bits, (double)bits / (double)head.size(), 100.0 * (double)used / (double)head.size());
-                        for (int c = 0; c <= 64; c += 4) fprintf(stderr, " [%d+]=%lld", c, (long long)(hist[c] + hist[c + 1 > 64 ? 64 : c + 1] * (c + 1 <= 64) ));
-                        fprintf(stderr, "\n");
+                        fprintf(stderr, "[skm_index_create] signatures: 2^%d slots of 128 bits; of the first %zu: %.2f bits set per slot, "
+                                "%.1f %% in use, %lld full\n", sig_bits, head.size() / 2, 2.0 * (double)bits / (double)head.size(),
+                                200.0 * (double)used / (double)head.size(), (long long)full);
                     }
                     ix->d.signatures = (const uint64_t *)ix->signatures;
                     ix->d.signature_shift = (uint32_t)(32 - sig_bits);
-                    ix->bytes += (int64_t)(2 * sizeof(uint64_t) << sig_bits);
+                    ix->bytes += (int64_t)sig_bytes;
                     ix->layout[7] = (int64_t)1 << sig_bits;
                 }
                 const char *no_succ = getenv("SKM_NO_SUCCESSORS");     // tuning aid: every junction k-mer looked up
