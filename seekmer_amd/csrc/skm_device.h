@@ -483,15 +483,19 @@ __device__ __forceinline__ Hop junction_successor(const SideVisit &at_side, bool
 // A read with a sequencing error in its first k bases is rolled through up to k k-mers that are not
 // in the table, and every one of them costs a sector of a bucket that has nothing to do with the
 // one before: the roll is the largest single item of the mapper's sector budget.  Consecutive k-mers
-// share their MINIMIZER -- here: the smallest hash among the 13-mers of the k-mer and of its reverse
-// complement, 26 values of which a k-mer and its successor share 24 -- for six steps on average,
-// so a small table indexed by that hash is read once for a run of k-mers.  (13 bases: with 11 there
+// share their MINIMIZER -- here: the smallest hash among the 15-mers of the k-mer and of its reverse
+// complement, 22 values of which a k-mer and its successor share 20 -- for five steps on average,
+// so a small table indexed by that hash is read once for a run of k-mers.  (15 bases: with 11 there
 // are 4 M possible minimizers of which a random order favours ~300 k, and 65 M k-mers saturate their
-// signatures.)  It holds, per slot, a 128-bit signature: two bits of it (signature_bits, from
+// signatures; 13, 14 and 15 measured 5.31, 5.15 and 5.13 ms per launch.)  It holds, per slot, a 128-bit signature: two bits of it (signature_bits, from
 // bucket_hash(canonical k-mer)) are set for every k-mer of the table whose minimizer hashes there.
 // A k-mer with one of its bits clear is not in the table -- no false negatives: slots that collide
 // only add bits --; one with both set is looked up as before.
-constexpr int MINIMIZER_BASES = 13;
+#ifndef SKM_MINIMIZER_BASES
+#define SKM_MINIMIZER_BASES 15
+#endif
+constexpr int MINIMIZER_BASES = SKM_MINIMIZER_BASES;
+static_assert(MINIMIZER_BASES >= 8 && MINIMIZER_BASES <= 15 && MINIMIZER_BASES < K, "a minimizer is hashed as a 32-bit word");
 constexpr int MINIMIZERS_PER_KMER = K - MINIMIZER_BASES + 1;      // 15 per strand
 __device__ __forceinline__ uint32_t mmer_hash(uint32_t mmer)
 {

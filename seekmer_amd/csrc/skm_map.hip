@@ -833,7 +833,10 @@ enum : int { A_START = 0, A_LOOKUP, A_MERGE, A_LEFT, A_RIGHT, A_EMIT, A_SCAN, N_
 #define SKM_SCAN_ROUNDS 5
 #endif
 constexpr int SCAN_ROUNDS = SKM_SCAN_ROUNDS;    // k-mers one round of the first-hit roll looks up together
-constexpr int SIGNED_CANDIDATES = 7;            // ... with the signatures in front: a window of k + 6 bases of the read
+#ifndef SKM_SIGNED_CANDIDATES
+#define SKM_SIGNED_CANDIDATES 8
+#endif
+constexpr int SIGNED_CANDIDATES = SKM_SIGNED_CANDIDATES;            // ... with the signatures in front: a window of k + 6 bases of the read
 
 
 constexpr int NCTX = MAP_CONTEXTS;    // unit contexts per block (LDS)
@@ -1119,11 +1122,10 @@ map_units_kernel(DevIndex ix, MapBatch b)
             } else if (valid && action == A_SCAN && BUCKETS && ix.signatures != nullptr) {
                 // ------------- _find_first_kmer's roll, :207-216, with the signatures in front of the bucket
                 // table (skm_device.h: kmer_min_hash): up to SIGNED_CANDIDATES k-mers of the read -- the one
-                // at hand and those its next bases make, a window of 32 bases -- ask the signature of their
-                // minimizer (a run of k-mers shares it: one or two sectors for the lot) whether they can be
-                // in the table at all; the few that can ask for the `low` words of their buckets together,
-                // and the judging goes in read order as in the plain roll below: the first hit is the one
-                // the reference's one-by-one roll stops at.
+                // at hand and those its next bases make, a window of k + SIGNED_CANDIDATES - 1 bases --
+                // ask the signature of their minimizer (a run of k-mers shares it: one or two sectors for
+                // the lot) whether they can be in the table at all; those that can are looked up in read
+                // order, so the first hit is the one the reference's one-by-one roll stops at.
                 constexpr int N = SIGNED_CANDIDATES;
                 uint32_t more = 0;
                 int m = 1;
